@@ -1,0 +1,136 @@
+"""Pins oracle/mps_oracle.py against vectors produced by the unmodified reference
+(tests/golden/make_golden.py).  CPU only.  Compares gauge-invariant quantities."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import mps_oracle as mo
+
+RTOL = 1e-9
+
+
+def close(a, b, rtol=RTOL, atol=None):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-300)
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol, err
+
+
+@pytest.mark.parametrize('name', gu.names('forward_'))
+def test_forward(name):
+    d = gu.load(name)
+    N, M, L, D = int(d['N']), int(d['M']), int(d['L']), int(d['D'])
+    for tag, X, l_pos in (('a_', d['X'], 0), ('b_', d['X2'], N - 1)):
+        st = mo.MPSState(N, D, L, M, gu.indexed(d, tag + 'core', N), l_pos)
+        f = mo.forward(st, X)
+        close(f, d[tag + 'f'])
+        envs = st.Renv if l_pos == 0 else st.Lenv
+        side = 'Renv' if l_pos == 0 else 'Lenv'
+        assert len(envs) == N - 1
+        for i, e in envs.items():
+            close(e, d['%s%s%d' % (tag, side, i)])
+
+
+def _step_kwargs(d):
+    return dict(lr=float(d['lr']), weight_dec=float(d['wd']), L2_flag=bool(d['L2_flag']),
+                act_fn=str(d['act_fn']), loss_fn=str(d['loss_fn']), T=float(d['T']),
+                trunc=str(d['policy']))
+
+
+def _check_step(d, pre, rec, f_new, st_after):
+    close(rec['B'], d[pre + 'B'])
+    close(rec['B_new'], d[pre + 'B_new'])
+    # dB exposed: (B_new - B)/lr
+    lr = float(d['lr'])
+    close((rec['B_new'] - rec['B']) / lr, (d[pre + 'B_new'] - d[pre + 'B']) / lr, rtol=1e-7)
+    close(f_new, d[pre + 'f_new'])
+    assert abs(rec['accuracy'] - float(d[pre + 'accuracy'])) < 1e-12
+    assert abs(rec['MAE'] - float(d[pre + 'MAE'])) <= 1e-9 * max(1.0, abs(float(d[pre + 'MAE'])))
+    if bool(d['L2_flag']):
+        close(rec['L2_grad'], d[pre + 'L2_grad'])
+        close(rec['L2_loss'], d[pre + 'L2_loss'])
+    close(rec['Bmat'], d[pre + 'Bmat'])           # pins the (i, j) matricisation order
+    close(rec['S'], d[pre + 'S'], rtol=1e-8)
+    assert list(st_after.bond) == [int(x) for x in d[pre + 'bond']]
+
+
+@pytest.mark.parametrize('name', gu.names('traj_'))
+def test_teacher_forced_steps(name):
+    """Every step restarted from the reference's own snapshot (cores + environments)."""
+    d = gu.load(name)
+    N, M, L, D = int(d['N']), int(d['M']), int(d['L']), int(d['D'])
+    kw = _step_kwargs(d)
+    y1h = mo.one_hot(d['y'], L)
+    for k in range(int(d['n_steps'])):
+        pre = 'st%d_' % k
+        l_pos = int(d[pre + 'l_pos'])
+        left_dir = bool(d[pre + 'left_dir'])
+        cores = gu.unflatten_cores(d[pre + 'cores_flat'], d[pre + 'bond_before'], l_pos, D, L)
+        st = mo.MPSState(N, D, L, M, cores, l_pos)
+        st.X = d['X']
+        st.Lenv, st.Renv = gu.step_envs(d, pre)
+        rec = {}
+        f_new = mo.sweep_step(st, d[pre + 'f_prev'], y1h, left_dir=left_dir, record=rec, **kw)
+        _check_step(d, pre, rec, f_new, st)
+        # truncated product against the reference's next snapshot of the two rewritten cores
+        p = rec['p']
+        if k + 1 < int(d['n_steps']) and bool(d['st%d_left_dir' % (k + 1)]) == left_dir:
+            nxt = 'st%d_' % (k + 1)
+            rc = gu.unflatten_cores(d[nxt + 'cores_flat'], d[nxt + 'bond_before'], int(d[nxt + 'l_pos']), D, L)
+            if not left_dir:
+                ref_prod = np.einsum('adk,kecl->adecl', rc[p], rc[p + 1])
+                my_prod = np.einsum('adk,kecl->adecl', st.cores[p], st.cores[p + 1])
+            else:
+                ref_prod = np.einsum('adkl,kec->adecl', rc[p], rc[p + 1])
+                my_prod = np.einsum('adkl,kec->adecl', st.cores[p], st.cores[p + 1])
+            close(my_prod, ref_prod, rtol=1e-8)
+
+
+@pytest.mark.parametrize('name', gu.names('traj_'))
+def test_free_running_trajectory(name):
+    """forward + whole sweeps from the initial cores only; also exercises the cached norm envs."""
+    d = gu.load(name)
+    N, M, L, D = int(d['N']), int(d['M']), int(d['L']), int(d['D'])
+    kw = _step_kwargs(d)
+    lr, wd, L2 = kw.pop('lr'), kw.pop('weight_dec'), kw.pop('L2_flag')
+    st = mo.MPSState(N, D, L, M, gu.indexed(d, 'init_core', N), 0)
+    k = 0
+    for sw in range(int(d['n_sweeps'])):
+        f = mo.forward(st, d['X'])
+        close(f, d['sw%d_f_forward' % sw], rtol=1e-7)
+        left_dir = bool(d['sw%d_left_dir' % sw])
+        assert left_dir == (st.l_pos == N - 1)
+        vh = [[], []]
+        f = mo.sweep(st, d['X'], d['y'], f, lr, wd, L2_flag=L2, left_dir=left_dir, var_hist=vh, **kw)
+        for j in range(N - 1):
+            assert abs(vh[0][j] - float(d['st%d_accuracy' % (k + j)])) < 1e-12
+            assert abs(vh[1][j] - float(d['st%d_MAE' % (k + j)])) < 1e-6
+        k += N - 1
+        close(f, d['st%d_f_new' % (k - 1)], rtol=1e-6)
+    assert st.l_pos == int(d['final_l_pos'])
+    close(mo.forward(st, d['X']), d['final_f'], rtol=1e-6)
+
+
+def test_reference_policy_crashes_for_L3():
+    """The unmodified reference raises at the last right step when D*L > D*left
+    (Network_class.py:914); the oracle mirrors it with ValueError under trunc='reference'."""
+    rng = np.random.default_rng(0)
+    N, M, L, D, b = 6, 3, 3, 2, 5
+    cores = mo.random_cores(N, M, D, L, rng=rng, scale=M * 0.64)
+    st = mo.MPSState(N, D, L, M, cores)
+    X = rng.random((b, N, D))
+    y = rng.integers(0, L, b)
+    f = mo.forward(st, X)
+    with pytest.raises(ValueError):
+        mo.sweep(st, X, y, f, 1e-3, 1e-3, trunc='reference')
+
+
+def test_shipped_model():
+    d = gu.load('shipped_diag_model')
+    N, M, L, D = int(d['N']), int(d['M']), int(d['L']), int(d['D'])
+    st = mo.MPSState(N, D, L, M, gu.indexed(d, 'core', N), int(d['l_pos']))
+    f = mo.forward(st, d['X'])
+    close(f, d['f'])
+    assert mo.accuracy(f, d['y']) == float(d['accuracy']) == 1.0
+    close(mo.apply_act_func(f, str(d['act_fn']), float(d['T'])), d['act'])
