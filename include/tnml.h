@@ -1,0 +1,152 @@
+/*
+ * tnml.h -- C ABI of libtnml_hip.so: the MI355X (gfx950) backend of the MPS two-site sweep
+ * optimiser.
+ *
+ * The reference (francescovidaich964/TensorNetworkForML) is pure Python/NumPy and has no FFI:
+ * its boundary for this path is the Python API of TensorNetwork/Network_class.py.  Each entry
+ * point below names the reference method (file:line under /root/reference/TensorNetwork) whose
+ * arithmetic it replaces; INTEGRATION.md shows the ctypes stub a maintainer of the reference
+ * would add to Network_class.py to call it.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative tnml_status on failure;
+ *     tnml_last_error() returns a thread-local, human readable message for the last failure;
+ *   - plain pointers and sizes only; host pointers unless a name ends in _dev;
+ *   - a tnml_ctx owns all device memory, one HIP stream and (optionally) one RCCL communicator;
+ *     one host thread per context; calls are stream-ordered and return after enqueueing unless
+ *     they hand data back to the host (those synchronise the stream);
+ *   - all tensors are float32 on the device; batch-independent norm environments and the
+ *     merged-tensor update/SVD run in float64 inside the kernels;
+ *   - canonical layouts (identical to oracle/mps_oracle.py):
+ *       bond[i]      dimension of the bond between site i and i+1, i = 0..N-2
+ *       core i       [ml][D][mr]      ml = bond[i-1] (1 at i = 0), mr = bond[i] (1 at i = N-1)
+ *       core l_pos   [ml][D][mr][L]   the label axis is last on the site that carries it
+ *       cores_flat   the N cores above concatenated in site order
+ *       X            [b][N][D]        as Network.forward receives it (Network_class.py:195)
+ *       f, g         [L][b]
+ *       env          [b][m]           on the host side of tnml_get_env
+ *       B            [ml][D][D][mr][L]  merged two-site tensor (a, d, d', c, l)
+ */
+#ifndef TNML_H
+#define TNML_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tnml_ctx tnml_ctx;
+
+typedef enum {
+  TNML_OK = 0,
+  TNML_ERR_ARG = -1,       /* bad argument / shape mismatch (the reference's AssertionError)   */
+  TNML_ERR_STATE = -2,     /* call not allowed in this state (the reference's Exception)       */
+  TNML_ERR_HIP = -3,       /* HIP runtime failure                                               */
+  TNML_ERR_NOGPU = -4,     /* no usable gfx950 device                                           */
+  TNML_ERR_COMM = -5,      /* RCCL failure                                                      */
+  TNML_ERR_SHAPE = -6,     /* reference truncation policy hits the reference's own ValueError   */
+  TNML_ERR_NONFINITE = -7  /* non-finite values reached the SVD (reference: LinAlgError)        */
+} tnml_status;
+
+/* activation / loss / truncation selectors (Network_class.py:127-133, :894-945) */
+enum { TNML_ACT_LINEAR = 0, TNML_ACT_SIGMOID = 1, TNML_ACT_SOFTMAX = 2 };
+enum { TNML_LOSS_MSE = 0, TNML_LOSS_CROSS_ENTROPY = 1, TNML_LOSS_FULL_CROSS_ENT = 2 };
+enum { TNML_TRUNC_REFERENCE = 0, TNML_TRUNC_FIXED = 1 };
+enum { TNML_SIDE_LEFT = 0, TNML_SIDE_RIGHT = 1 };
+
+/* what tnml_get_step_debug can hand back about the most recent sweep step */
+enum {
+  TNML_DBG_B = 0,        /* merged tensor before the update        [ml][D][D][mr][L]            */
+  TNML_DBG_DB_RAW = 1,   /* bond gradient before weight decay      same shape                    */
+  TNML_DBG_B_NEW = 2,    /* updated, un-truncated merged tensor    same shape                    */
+  TNML_DBG_SIGMA = 3,    /* all singular values, descending        [min(rows, cols)]             */
+  TNML_DBG_L2 = 4,       /* {L2 loss term, sum|B|, sum|dB|, jacobi sweeps, n rotations}  [5]     */
+  TNML_DBG_L2_GRAD = 5   /* 2*wd*Ln.B.Rn (or wd*B)                 same shape as B               */
+};
+
+const char *tnml_last_error(void);
+const char *tnml_version(void);
+/* number of visible HIP devices (0 without a GPU; never fails) */
+int tnml_device_count(void);
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+/* Network.__init__ (Network_class.py:84-191) minus the random init, which stays on the host.
+ * b_capacity: largest batch a later tnml_set_input may bring (buffers grow if exceeded). */
+int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_capacity, int device);
+int tnml_destroy(tnml_ctx *ctx);
+int tnml_synchronize(tnml_ctx *ctx);
+
+/* ---- multi-GPU: batch shards, one RCCL all-reduce of the bond gradient per step ---------- */
+/* 128-byte RCCL unique id, created on rank 0 and handed to every rank by the caller. */
+int tnml_comm_unique_id(void *uid128);
+int tnml_comm_init(tnml_ctx *ctx, int rank, int nranks, const void *uid128);
+
+/* ---- parameters ------------------------------------------------------------------------- */
+/* replaces assignments to Network.As / Network.l_pos */
+int tnml_set_cores(tnml_ctx *ctx, const float *cores_flat, size_t n_floats, const int32_t *bond,
+                   int l_pos);
+int tnml_cores_size(tnml_ctx *ctx, size_t *n_floats);
+int tnml_get_cores(tnml_ctx *ctx, float *cores_flat, size_t capacity, int32_t *bond, int *l_pos);
+/* every core *= factor: the calibration loop of Network.__init__ (Network_class.py:175-176) */
+int tnml_scale_cores(tnml_ctx *ctx, double factor);
+
+/* ---- batch ------------------------------------------------------------------------------ */
+/* X [b][N][D] float32, y [b] int32 (may be NULL when only forward is wanted) */
+int tnml_set_input(tnml_ctx *ctx, const float *X, const int32_t *y, int b);
+
+/* ---- hot path --------------------------------------------------------------------------- */
+/* Network.forward (Network_class.py:195-258): builds the environment stack for the current
+ * l_pos (0 -> right environments, N-1 -> left environments) and f.  f_out [L][b] may be NULL. */
+int tnml_forward(tnml_ctx *ctx, float *f_out);
+/* max |f| over the (global) batch after a forward: Network_class.py:169 */
+int tnml_f_absmax(tnml_ctx *ctx, double *out);
+/* the f the next sweep step starts from (Network.sweep's argument f, Network_class.py:384) */
+int tnml_set_f(tnml_ctx *ctx, const float *f);
+int tnml_get_f(tnml_ctx *ctx, float *f_out);
+
+/* Network.sweep / sweep_step / update_B / tensor_svd / compute_L2_reg
+ * (Network_class.py:384-436, 440-573, 577-763, 839-962, 966-1179): n_steps two-site steps in
+ * the given direction, starting at the current l_pos.  A full sweep is n_steps = N-1 right
+ * after tnml_forward.
+ *   first_of_sweep  non-zero: reset the environment list grown by this direction (:426-429)
+ *   metrics_out     [n_steps][2] = (accuracy, MAE) per step (var_hist, :739-750), or NULL
+ *   f_out           [L][b] output recomputed from the last updated, un-truncated B (:494-523) */
+int tnml_sweep(tnml_ctx *ctx, int left_dir, int n_steps, int first_of_sweep, float lr,
+               float weight_dec, int l2_flag, int act_fn, int loss_fn, float T, int trunc_policy,
+               float *metrics_out, float *f_out);
+
+/* Network.apply_act_func / compute_loss_derivate on the device-resident f (:767-835);
+ * act_out, lossder_out [L][b], either may be NULL */
+int tnml_activation(tnml_ctx *ctx, int act_fn, int loss_fn, float T, float *act_out,
+                    float *lossder_out);
+
+/* ---- inspection (API parity: Network.r_cum_contraction / l_cum_contraction) -------------- */
+int tnml_get_env(tnml_ctx *ctx, int side, int site, float *out, size_t capacity, int *m);
+/* capture B, dB, B_new, sigma of every step into a debug block (tests only; off by default) */
+int tnml_debug_enable(tnml_ctx *ctx, int on);
+int tnml_get_step_debug(tnml_ctx *ctx, int what, double *out, size_t capacity, size_t *n);
+int tnml_l_pos(tnml_ctx *ctx);
+int tnml_batch(tnml_ctx *ctx);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* HIP-event timing on the context's own stream (torch.cuda.Event would not see it) */
+int tnml_timer_start(tnml_ctx *ctx);
+int tnml_timer_stop(tnml_ctx *ctx, double *elapsed_ms);
+/* accumulated per-kernel device time (ms) and launch counts since the last reset, measured with
+ * HIP events around each launch when profiling is enabled (slows the sweep; bench only)
+ *   which: 0 forward chain, 1 wide step kernel, 2 reduce kernel, 3 narrow (update+SVD) kernel */
+int tnml_profile_enable(tnml_ctx *ctx, int on);
+int tnml_profile_get(tnml_ctx *ctx, int which, double *ms, long long *launches);
+int tnml_profile_reset(tnml_ctx *ctx);
+
+/* Host-side planning helper, exported so that CPU tests can check the bond bookkeeping without a
+ * GPU: truncation rank kept by tensor_svd (Network_class.py:894-945) for a step on sites
+ * (p, p+1).  Returns m >= 1, or TNML_ERR_SHAPE where the reference itself raises. */
+int tnml_trunc_rank(int policy, int left_dir, int p, int N, int ml, int D, int mr, int L, int M);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNML_H */

@@ -1,0 +1,829 @@
+// Host side of libtnml_hip.so: context, device buffers, per-step planning in the sweep-relative
+// frame, the sweep driver (wide -> reduce -> [RCCL all-reduce] -> narrow per step, all enqueued on
+// one stream without host synchronisation) and the C ABI of include/tnml.h.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "tnml_internal.h"
+
+using namespace tnml;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(TNML_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
+                                      hipGetErrorString(e_), __FILE__, __LINE__);              \
+  } while (0)
+
+#define NCCL_TRY(expr)                                                                         \
+  do {                                                                                         \
+    ncclResult_t r_ = (expr);                                                                  \
+    if (r_ != ncclSuccess) return fail(TNML_ERR_COMM, "%s failed: %s (%s:%d)", #expr,         \
+                                       ncclGetErrorString(r_), __FILE__, __LINE__);            \
+  } while (0)
+
+struct tnml_ctx {
+  int N = 0, D = 0, L = 0, Mmax = 0;   // Mmax = buffer capacity per bond
+  int Mpol = 0;                         // the M of Network(N, M, ...): fixed-policy rank
+  int b = 0, b_pad = 0, b_cap = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
+  // host bookkeeping
+  std::vector<int> bond;
+  int l_pos = 0;
+  bool cores_set = false;
+  bool have_input = false, have_labels = false;
+  bool envs_valid_L = false, envs_valid_R = false;  // forward built the stack this side
+  bool Ln_valid = false, Rn_valid = false;
+  bool f_current = false;     // ctx->f holds the f the next step must start from
+  bool Bnew_valid = false;    // ctx->Bnew holds the updated B of the previous step
+  int prev_h = 0, prev_g = 0; // dims of Bnew (relative frame)
+  int prev_left_dir = 0, prev_p = -1;
+  int last_bsize = 0, last_n = 0, last_h = 0, last_g = 0, last_left_dir = 0;
+  bool debug = false, profile = false;
+  double prof_ms[4] = {0, 0, 0, 0};
+  long long prof_n[4] = {0, 0, 0, 0};
+  // device buffers
+  size_t core_stride = 0, lab_elems = 0, bmax = 0;
+  float *X = nullptr, *Xstage = nullptr;
+  int *y = nullptr;
+  float *f = nullptr, *ftmp = nullptr, *ftmp2 = nullptr;
+  float *Lenv = nullptr, *Renv = nullptr;
+  float *cores = nullptr, *lab[2] = {nullptr, nullptr};
+  int lab_cur = 0;
+  double *Ln = nullptr, *Rn = nullptr;
+  float *Bnew = nullptr, *slabs = nullptr, *red = nullptr, *metrics = nullptr, *scal = nullptr;
+  int slab_stride = 0, nblk_cap = 0, metrics_cap = 0;
+  double *dbg = nullptr;
+  size_t dbg_elems = 0;
+  int *status = nullptr;
+  void *tables = nullptr;      // device scratch for ChainSite / NormChainSite tables
+  size_t tables_bytes = 0;
+  // multi-GPU
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+
+  int ml(int i) const { return i == 0 ? 1 : bond[i - 1]; }
+  int mr(int i) const { return i == N - 1 ? 1 : bond[i]; }
+  float *env_slot(float *base, int site) const { return base + (size_t)site * Mmax * b_pad; }
+  long long env_off(int site) const { return (long long)site * Mmax * b_pad; }
+  float *core_slot(int site) const { return cores + (size_t)site * core_stride; }
+  double *norm_slot(double *base, int site) const { return base + (size_t)site * Mmax * Mmax; }
+};
+
+// ---------------------------------------------------------------------------------------------
+extern "C" const char *tnml_last_error(void) { return g_err.c_str(); }
+extern "C" const char *tnml_version(void) { return "tnml-hip 0.1 (gfx950)"; }
+
+extern "C" int tnml_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int tnml_trunc_rank(int policy, int left_dir, int p, int N, int ml, int D, int mr, int L, int M) {
+  // Network_class.py:894-910 (right sweep) and :931-945 (left sweep)
+  const int rows = left_dir ? D * ml * L : D * ml;
+  const int cols = left_dir ? D * mr : D * mr * L;
+  const int nS = std::min(rows, cols);
+  if (policy == TNML_TRUNC_FIXED) return std::min(M, nS);
+  const bool first = (p == 0), last = (p == N - 2);
+  if (!left_dir) {
+    if (first) return rows == nS ? nS : TNML_ERR_SHAPE;   // only Vh cut, U stays rows x rows
+    if (!last) return ml <= nS ? ml : TNML_ERR_SHAPE;     // m = left bond of the merged tensor
+    return cols == nS ? nS : TNML_ERR_SHAPE;              // only U cut, Vh stays cols x cols
+  }
+  if (last) return cols == nS ? nS : TNML_ERR_SHAPE;
+  if (!first) return ml <= nS ? ml : TNML_ERR_SHAPE;
+  return rows == nS ? nS : TNML_ERR_SHAPE;
+}
+
+static int alloc_batch_buffers(tnml_ctx *c, int b_cap) {
+  const int b_pad = (b_cap + 63) / 64 * 64;
+  auto freep = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  freep(c->X); freep(c->Xstage); freep(c->y); freep(c->f); freep(c->ftmp); freep(c->ftmp2);
+  freep(c->Lenv); freep(c->Renv); freep(c->slabs);
+  c->b_cap = b_cap;
+  c->b_pad = b_pad;
+  const size_t env_elems = (size_t)c->N * c->Mmax * b_pad;
+  HIP_TRY(hipMalloc(&c->X, (size_t)c->N * b_pad * c->D * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->Xstage, (size_t)c->N * b_pad * c->D * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->y, (size_t)b_pad * sizeof(int)));
+  HIP_TRY(hipMalloc(&c->f, (size_t)c->L * b_pad * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->ftmp, (size_t)c->L * b_pad * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->ftmp2, (size_t)c->L * b_pad * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->Lenv, env_elems * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->Renv, env_elems * sizeof(float)));
+  c->nblk_cap = b_pad / kTS;
+  HIP_TRY(hipMalloc(&c->slabs, (size_t)c->nblk_cap * c->slab_stride * sizeof(float)));
+  HIP_TRY(hipMemsetAsync(c->y, 0, (size_t)b_pad * sizeof(int), c->stream));
+  HIP_TRY(hipMemsetAsync(c->f, 0, (size_t)c->L * b_pad * sizeof(float), c->stream));
+  c->have_input = c->have_labels = false;
+  c->envs_valid_L = c->envs_valid_R = false;
+  c->f_current = false;
+  return TNML_OK;
+}
+
+extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_capacity, int device) {
+  if (!out) return fail(TNML_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (N < 2 || L < 1 || Mmax < 1 || b_capacity < 1) return fail(TNML_ERR_ARG, "bad sizes N=%d L=%d M=%d b=%d", N, L, Mmax, b_capacity);
+  if (D != kD) return fail(TNML_ERR_ARG, "this build is specialised for D == %d (got %d)", kD, D);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(TNML_ERR_NOGPU, "no HIP device visible: the HIP path has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(TNML_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(TNML_ERR_NOGPU, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+  tnml_ctx *c = new tnml_ctx();
+  // Under the reference truncation policy the bond next to a chain end becomes len(S) =
+  // min(D*left, D*L) (Network_class.py:907-910), which exceeds M when M < D*L (the MNIST script
+  // runs M = 3, L = 2): size every buffer for that.
+  c->Mpol = Mmax;
+  Mmax = std::max(Mmax, D * std::min(L, Mmax));
+  c->N = N; c->D = D; c->L = L; c->Mmax = Mmax; c->device = device;
+  c->bond.assign(N - 1, 1);
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipEventCreate(&c->pev0)); HIP_TRY(hipEventCreate(&c->pev1));
+  c->core_stride = (size_t)Mmax * D * Mmax;
+  c->lab_elems = (size_t)Mmax * D * Mmax * L;
+  c->bmax = (size_t)Mmax * D * D * Mmax * L;
+  c->slab_stride = (int)((c->bmax + kMetricSlots + 63) / 64 * 64);
+  HIP_TRY(hipMalloc(&c->cores, (size_t)N * c->core_stride * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->lab[0], c->lab_elems * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->lab[1], c->lab_elems * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->Ln, (size_t)N * Mmax * Mmax * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->Rn, (size_t)N * Mmax * Mmax * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->Bnew, c->bmax * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->red, (size_t)c->slab_stride * sizeof(float)));
+  c->metrics_cap = N;
+  HIP_TRY(hipMalloc(&c->metrics, (size_t)c->metrics_cap * 2 * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->scal, 64 * sizeof(float)));
+  c->dbg_elems = 4 * c->bmax + 64 + 16;
+  HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->status, sizeof(int)));
+  HIP_TRY(hipMemsetAsync(c->status, 0, sizeof(int), c->stream));
+  c->tables_bytes = (size_t)N * std::max(sizeof(ChainSite), sizeof(NormChainSite));
+  HIP_TRY(hipMalloc(&c->tables, c->tables_bytes));
+  int rc = alloc_batch_buffers(c, b_capacity);
+  if (rc != TNML_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = c;
+  return TNML_OK;
+}
+
+extern "C" int tnml_destroy(tnml_ctx *c) {
+  if (!c) return TNML_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  void *ptrs[] = {c->X, c->Xstage, c->y, c->f, c->ftmp, c->ftmp2, c->Lenv, c->Renv, c->cores, c->lab[0], c->lab[1],
+                  c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->pev0) (void)hipEventDestroy(c->pev0);
+  if (c->pev1) (void)hipEventDestroy(c->pev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return TNML_OK;
+}
+
+extern "C" int tnml_synchronize(tnml_ctx *c) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TNML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU
+// ---------------------------------------------------------------------------------------------
+extern "C" int tnml_comm_unique_id(void *uid128) {
+  if (!uid128) return fail(TNML_ERR_ARG, "uid buffer is NULL");
+  static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is expected to be 128 bytes");
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  memcpy(uid128, &id, sizeof id);
+  return TNML_OK;
+}
+
+extern "C" int tnml_comm_init(tnml_ctx *c, int rank, int nranks, const void *uid128) {
+  if (!c || !uid128) return fail(TNML_ERR_ARG, "NULL argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(TNML_ERR_ARG, "bad rank %d / %d", rank, nranks);
+  HIP_TRY(hipSetDevice(c->device));
+  c->rank = rank;
+  c->nranks = nranks;
+  if (nranks == 1) return TNML_OK;
+  ncclUniqueId id;
+  memcpy(&id, uid128, sizeof id);
+  NCCL_TRY(ncclCommInitRank(&c->comm, nranks, id, rank));
+  return TNML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------------------------
+static size_t core_elems(const tnml_ctx *c, const std::vector<int> &bond, int i, int l_pos) {
+  const int ml = i == 0 ? 1 : bond[i - 1], mr = i == c->N - 1 ? 1 : bond[i];
+  return (size_t)ml * c->D * mr * (i == l_pos ? c->L : 1);
+}
+
+extern "C" int tnml_set_cores(tnml_ctx *c, const float *flat, size_t n_floats, const int32_t *bond, int l_pos) {
+  if (!c || !flat || !bond) return fail(TNML_ERR_ARG, "NULL argument");
+  if (l_pos < 0 || l_pos >= c->N) return fail(TNML_ERR_ARG, "l_pos %d out of range", l_pos);
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<int> nb(bond, bond + c->N - 1);
+  size_t total = 0;
+  for (int i = 0; i < c->N; ++i) {
+    const int ml = i == 0 ? 1 : nb[i - 1], mr = i == c->N - 1 ? 1 : nb[i];
+    if (ml < 1 || mr < 1) return fail(TNML_ERR_ARG, "bond dimension < 1 at site %d", i);
+    const size_t ne = core_elems(c, nb, i, l_pos);
+    if (i == l_pos ? ne > c->lab_elems : ne > c->core_stride)
+      return fail(TNML_ERR_ARG, "core %d (%d x %d x %d) exceeds the capacity for M = %d", i, ml, c->D, mr, c->Mmax);
+    total += ne;
+  }
+  if (total != n_floats) return fail(TNML_ERR_ARG, "cores_flat holds %zu floats, bonds imply %zu", n_floats, total);
+  std::vector<float> stage((size_t)c->N * c->core_stride, 0.f);
+  size_t off = 0;
+  const float *labsrc = nullptr;
+  size_t labn = 0;
+  for (int i = 0; i < c->N; ++i) {
+    const size_t ne = core_elems(c, nb, i, l_pos);
+    if (i == l_pos) { labsrc = flat + off; labn = ne; }
+    else memcpy(stage.data() + (size_t)i * c->core_stride, flat + off, ne * sizeof(float));
+    off += ne;
+  }
+  HIP_TRY(hipMemcpyAsync(c->cores, stage.data(), stage.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->lab[c->lab_cur], labsrc, labn * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->bond = nb;
+  c->l_pos = l_pos;
+  c->cores_set = true;
+  c->envs_valid_L = c->envs_valid_R = false;
+  c->Ln_valid = c->Rn_valid = false;
+  c->f_current = false;
+  c->Bnew_valid = false;
+  return TNML_OK;
+}
+
+extern "C" int tnml_cores_size(tnml_ctx *c, size_t *n_floats) {
+  if (!c || !n_floats) return fail(TNML_ERR_ARG, "NULL argument");
+  size_t total = 0;
+  for (int i = 0; i < c->N; ++i) total += core_elems(c, c->bond, i, c->l_pos);
+  *n_floats = total;
+  return TNML_OK;
+}
+
+extern "C" int tnml_get_cores(tnml_ctx *c, float *flat, size_t capacity, int32_t *bond, int *l_pos) {
+  if (!c || !flat) return fail(TNML_ERR_ARG, "NULL argument");
+  if (!c->cores_set) return fail(TNML_ERR_STATE, "cores were never set");
+  HIP_TRY(hipSetDevice(c->device));
+  size_t total = 0;
+  tnml_cores_size(c, &total);
+  if (capacity < total) return fail(TNML_ERR_ARG, "capacity %zu < %zu floats", capacity, total);
+  std::vector<float> stage((size_t)c->N * c->core_stride);
+  std::vector<float> labh(c->lab_elems);
+  HIP_TRY(hipMemcpyAsync(stage.data(), c->cores, stage.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(labh.data(), c->lab[c->lab_cur], labh.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  size_t off = 0;
+  for (int i = 0; i < c->N; ++i) {
+    const size_t ne = core_elems(c, c->bond, i, c->l_pos);
+    memcpy(flat + off, i == c->l_pos ? labh.data() : stage.data() + (size_t)i * c->core_stride, ne * sizeof(float));
+    off += ne;
+  }
+  if (bond) for (int i = 0; i < c->N - 1; ++i) bond[i] = c->bond[i];
+  if (l_pos) *l_pos = c->l_pos;
+  return TNML_OK;
+}
+
+extern "C" int tnml_scale_cores(tnml_ctx *c, double factor) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  if (!c->cores_set) return fail(TNML_ERR_STATE, "cores were never set");
+  HIP_TRY(hipSetDevice(c->device));
+  launch_scale(c->cores, (size_t)c->N * c->core_stride, (float)factor, c->stream);
+  launch_scale(c->lab[c->lab_cur], c->lab_elems, (float)factor, c->stream);
+  HIP_TRY(hipGetLastError());
+  c->envs_valid_L = c->envs_valid_R = false;
+  c->Ln_valid = c->Rn_valid = false;
+  c->f_current = false;
+  c->Bnew_valid = false;
+  return TNML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch
+// ---------------------------------------------------------------------------------------------
+extern "C" int tnml_set_input(tnml_ctx *c, const float *X, const int32_t *y, int b) {
+  if (!c || !X) return fail(TNML_ERR_ARG, "NULL argument");
+  if (b < 1) return fail(TNML_ERR_ARG, "empty batch");
+  if (y)
+    for (int i = 0; i < b; ++i)
+      if (y[i] < 0 || y[i] >= c->L) return fail(TNML_ERR_ARG, "label %d of sample %d outside [0, %d)", y[i], i, c->L);
+  HIP_TRY(hipSetDevice(c->device));
+  if (b > c->b_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = alloc_batch_buffers(c, b);
+    if (rc != TNML_OK) return rc;
+  }
+  // keep the padding of a previous, larger batch from leaking: b_pad is per-capacity, the live
+  // batch is [0, b); kernels mask samples >= b.
+  c->b = b;
+  HIP_TRY(hipMemcpyAsync(c->Xstage, X, (size_t)b * c->N * c->D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  launch_transpose_input(c->Xstage, c->X, b, c->b_pad, c->N, c->stream);
+  HIP_TRY(hipGetLastError());
+  if (y) {
+    HIP_TRY(hipMemsetAsync(c->y, 0, (size_t)c->b_pad * sizeof(int), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->y, y, (size_t)b * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));   // X / y host buffers may be released by the caller
+  c->have_input = true;
+  c->have_labels = (y != nullptr);
+  c->envs_valid_L = c->envs_valid_R = false;
+  c->f_current = false;
+  c->Bnew_valid = false;
+  return TNML_OK;
+}
+
+static int copy_f_out(tnml_ctx *c, const float *src_dev, float *f_out) {
+  // [L][b_pad] on the device -> [L][b] on the host
+  HIP_TRY(hipMemcpy2DAsync(f_out, (size_t)c->b * sizeof(float), src_dev, (size_t)c->b_pad * sizeof(float),
+                           (size_t)c->b * sizeof(float), c->L, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TNML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+extern "C" int tnml_forward(tnml_ctx *c, float *f_out) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  if (!c->cores_set) return fail(TNML_ERR_STATE, "cores were never set");
+  if (!c->have_input) return fail(TNML_ERR_STATE, "no input batch: call tnml_set_input first");
+  if (c->l_pos != 0 && c->l_pos != c->N - 1)
+    return fail(TNML_ERR_STATE, "forward should not be called if l has an intermediate position (l_pos = %d)", c->l_pos);
+  HIP_TRY(hipSetDevice(c->device));
+  const int N = c->N, D = c->D, L = c->L;
+  std::vector<ChainSite> tab(N);
+  const bool right_envs = (c->l_pos == 0);
+  for (int k = 0; k < N; ++k) {
+    ChainSite cs{};
+    const int i = right_envs ? N - 1 - k : k;       // chain order
+    const int ml = c->ml(i), mr = c->mr(i);
+    cs.x_site = i;
+    const bool lab = (k == N - 1);
+    cs.is_label = lab;
+    cs.core_off = lab ? 0 : (int)((size_t)i * c->core_stride);
+    if (right_envs) {
+      cs.n_in = mr;
+      if (!lab) { cs.n_out = ml; cs.s_in = 1; cs.s_d = mr; cs.s_out = D * mr; cs.env_out_off = c->env_off(i); }
+      else { cs.n_out = L; cs.s_in = L; cs.s_d = mr * L; cs.s_out = 1; cs.env_out_off = -1; }
+    } else {
+      cs.n_in = ml;
+      if (!lab) { cs.n_out = mr; cs.s_in = D * mr; cs.s_d = mr; cs.s_out = 1; cs.env_out_off = c->env_off(i); }
+      else { cs.n_out = L; cs.s_in = D * L; cs.s_d = L; cs.s_out = 1; cs.env_out_off = -1; }
+    }
+    tab[k] = cs;
+  }
+  HIP_TRY(hipMemcpyAsync(c->tables, tab.data(), tab.size() * sizeof(ChainSite), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));   // tab is a stack object
+  if (c->profile) HIP_TRY(hipEventRecord(c->pev0, c->stream));
+  launch_env_chain((const ChainSite *)c->tables, N, c->cores, c->lab[c->lab_cur], c->X,
+                   right_envs ? c->Renv : c->Lenv, c->f, c->b, c->b_pad, L, c->Mmax, c->stream);
+  HIP_TRY(hipGetLastError());
+  if (c->profile) {
+    HIP_TRY(hipEventRecord(c->pev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->pev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->pev0, c->pev1));
+    c->prof_ms[0] += ms; c->prof_n[0]++;
+  }
+  c->envs_valid_R = right_envs;
+  c->envs_valid_L = !right_envs;
+  c->f_current = true;
+  c->Bnew_valid = false;
+  if (f_out) return copy_f_out(c, c->f, f_out);
+  return TNML_OK;
+}
+
+extern "C" int tnml_f_absmax(tnml_ctx *c, double *out) {
+  if (!c || !out) return fail(TNML_ERR_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  launch_absmax(c->f, c->L, c->b, c->b_pad, c->scal, c->stream);
+  HIP_TRY(hipGetLastError());
+  if (c->comm) NCCL_TRY(ncclAllReduce(c->scal, c->scal, 1, ncclFloat, ncclMax, c->comm, c->stream));
+  float v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, c->scal, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = v;
+  return TNML_OK;
+}
+
+extern "C" int tnml_set_f(tnml_ctx *c, const float *f) {
+  if (!c || !f) return fail(TNML_ERR_ARG, "NULL argument");
+  if (!c->have_input) return fail(TNML_ERR_STATE, "no input batch");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy2DAsync(c->f, (size_t)c->b_pad * sizeof(float), f, (size_t)c->b * sizeof(float),
+                           (size_t)c->b * sizeof(float), c->L, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->f_current = true;
+  return TNML_OK;
+}
+
+extern "C" int tnml_get_f(tnml_ctx *c, float *f_out) {
+  if (!c || !f_out) return fail(TNML_ERR_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  return copy_f_out(c, c->f, f_out);
+}
+
+extern "C" int tnml_activation(tnml_ctx *c, int act_fn, int loss_fn, float T, float *act_out, float *lossder_out) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  launch_activation(c->f, c->have_labels ? c->y : nullptr, c->L, c->b, c->b_pad, act_fn, loss_fn, T, c->ftmp,
+                    c->ftmp2, c->stream);
+  HIP_TRY(hipGetLastError());
+  if (act_out) { int rc = copy_f_out(c, c->ftmp, act_out); if (rc) return rc; }
+  if (lossder_out) { int rc = copy_f_out(c, c->ftmp2, lossder_out); if (rc) return rc; }
+  return TNML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// norm environments of the side a sweep runs towards (only when not inherited from the last sweep)
+// ---------------------------------------------------------------------------------------------
+static int build_norm_chain(tnml_ctx *c, bool right_side) {
+  // right_side: Rn[i] for i = N-1 .. 1 (sites i..N-1);  else Ln[i] for i = 0 .. N-2 (sites 0..i)
+  const int N = c->N, D = c->D;
+  std::vector<NormChainSite> tab;
+  for (int k = 0; k < N - 1; ++k) {
+    const int i = right_side ? N - 1 - k : k;
+    if (i == c->l_pos) break;                       // never crosses the label site
+    NormChainSite ns{};
+    const int ml = c->ml(i), mr = c->mr(i);
+    ns.core_off = (int)((size_t)i * c->core_stride);
+    if (right_side) { ns.n_in = mr; ns.n_out = ml; ns.s_in = 1; ns.s_d = mr; ns.s_out = D * mr; }
+    else { ns.n_in = ml; ns.n_out = mr; ns.s_in = D * mr; ns.s_d = mr; ns.s_out = 1; }
+    ns.env_out_off = (long long)i * c->Mmax * c->Mmax;
+    tab.push_back(ns);
+  }
+  if (tab.empty()) return TNML_OK;
+  HIP_TRY(hipMemcpyAsync(c->tables, tab.data(), tab.size() * sizeof(NormChainSite), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  launch_norm_chain((const NormChainSite *)c->tables, (int)tab.size(), c->cores, right_side ? c->Rn : c->Ln, c->Mmax,
+                    c->stream);
+  HIP_TRY(hipGetLastError());
+  return TNML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the sweep
+// ---------------------------------------------------------------------------------------------
+struct StepPlan {
+  int p, k, sb, sa, h, g, s, m;
+  WideParams w;
+  NarrowParams n;
+};
+
+static void prof_begin(tnml_ctx *c) { if (c->profile) (void)hipEventRecord(c->pev0, c->stream); }
+static void prof_end(tnml_ctx *c, int which) {
+  if (!c->profile) return;
+  (void)hipEventRecord(c->pev1, c->stream);
+  (void)hipEventSynchronize(c->pev1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, c->pev0, c->pev1);
+  c->prof_ms[which] += ms;
+  c->prof_n[which]++;
+}
+
+// f-part operands for "the step that just ended" seen from relative step index k (k >= 1):
+// fills hp, gp, Hprev, Gprev, x_km1, x_k, Bprev of `w`.
+static void fill_prev_operands(tnml_ctx *c, WideParams &w, int left_dir, int p_prev) {
+  // previous step acted on sites (p_prev, p_prev+1)
+  const int N = c->N;
+  float *beh = left_dir ? c->Renv : c->Lenv;     // stack the sweep grows
+  float *ahe = left_dir ? c->Lenv : c->Renv;     // stack forward built
+  const int sbp = left_dir ? p_prev + 1 : p_prev, sap = left_dir ? p_prev : p_prev + 1;
+  w.hp = c->prev_h;
+  w.gp = c->prev_g;
+  const int beh_site = left_dir ? p_prev + 2 : p_prev - 1;   // env slot holding H of the previous step
+  const int ahe_site = left_dir ? p_prev - 1 : p_prev + 2;   // env slot holding G of the previous step
+  w.Hprev = (beh_site >= 0 && beh_site <= N - 1) ? c->env_slot(beh, beh_site) : nullptr;
+  w.Gprev = (ahe_site >= 0 && ahe_site <= N - 1) ? c->env_slot(ahe, ahe_site) : nullptr;
+  w.x_km1 = c->X + (size_t)sbp * c->b_pad * c->D;
+  w.x_k = c->X + (size_t)sap * c->b_pad * c->D;
+  w.Bprev = c->Bnew;
+}
+
+extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep, float lr, float weight_dec,
+                          int l2_flag, int act_fn, int loss_fn, float T, int trunc_policy, float *metrics_out,
+                          float *f_out) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  if (!c->cores_set) return fail(TNML_ERR_STATE, "cores were never set");
+  if (!c->have_input || !c->have_labels) return fail(TNML_ERR_STATE, "a sweep needs inputs and labels (tnml_set_input)");
+  if (n_steps < 1) return fail(TNML_ERR_ARG, "n_steps < 1");
+  if (act_fn < 0 || act_fn > 2 || loss_fn < 0 || loss_fn > 2) return fail(TNML_ERR_ARG, "unknown activation / loss");
+  if (trunc_policy != TNML_TRUNC_REFERENCE && trunc_policy != TNML_TRUNC_FIXED) return fail(TNML_ERR_ARG, "unknown truncation policy");
+  left_dir = left_dir ? 1 : 0;
+  const int N = c->N, D = c->D, L = c->L;
+  HIP_TRY(hipSetDevice(c->device));
+  if (left_dir ? !(c->l_pos >= 1 && c->l_pos - n_steps >= 0) : !(c->l_pos + n_steps <= N - 1))
+    return fail(TNML_ERR_STATE, "position not allowed for %s sweep step (l_pos = %d, n_steps = %d)",
+                left_dir ? "left" : "right", c->l_pos, n_steps);
+  if (!(left_dir ? c->envs_valid_L : c->envs_valid_R))
+    return fail(TNML_ERR_STATE, "the %s environments are not built for this batch: call tnml_forward at l_pos = %d first",
+                left_dir ? "left" : "right", left_dir ? N - 1 : 0);
+  if (first_of_sweep) {
+    if ((left_dir && c->l_pos != N - 1) || (!left_dir && c->l_pos != 0))
+      return fail(TNML_ERR_STATE, "first_of_sweep set but l_pos = %d", c->l_pos);
+    c->Bnew_valid = false;
+  } else if (!c->Bnew_valid || c->prev_left_dir != left_dir) {
+    return fail(TNML_ERR_STATE, "mid-sweep continuation without a preceding step in the same direction");
+  }
+  if (!c->f_current && !c->Bnew_valid) return fail(TNML_ERR_STATE, "no f to start from: call tnml_forward or tnml_set_f");
+  if (n_steps > c->metrics_cap) return fail(TNML_ERR_ARG, "n_steps > N");
+  // norm environments towards which the sweep runs
+  if (l2_flag) {
+    if (!left_dir && !c->Rn_valid) { int rc = build_norm_chain(c, true); if (rc) return rc; c->Rn_valid = true; }
+    if (left_dir && !c->Ln_valid) { int rc = build_norm_chain(c, false); if (rc) return rc; c->Ln_valid = true; }
+  }
+  const int nblk = c->b_pad / kTS;
+  float *beh = left_dir ? c->Renv : c->Lenv;
+  float *ahe = left_dir ? c->Lenv : c->Renv;
+  double *nbeh = left_dir ? c->Rn : c->Ln;
+  double *nahe = left_dir ? c->Ln : c->Rn;
+
+  for (int step = 0; step < n_steps; ++step) {
+    const int l = c->l_pos;
+    const int p = left_dir ? l - 1 : l;
+    const int k = left_dir ? (N - 2 - p) : p;
+    const int sb = left_dir ? p + 1 : p, sa = left_dir ? p : p + 1;
+    const int h = left_dir ? c->mr(p + 1) : c->ml(p);
+    const int g = left_dir ? c->ml(p) : c->mr(p + 1);
+    const int s = c->bond[p];
+    const int m = tnml_trunc_rank(trunc_policy, left_dir, p, N, c->ml(p), D, c->mr(p + 1), L, c->Mpol);
+    if (m < 0) return fail(TNML_ERR_SHAPE, "shapes not aligned: the reference's un-truncated SVD factor does not fit "
+                                           "at sites (%d, %d) (Network_class.py:914 / :949)", p, p + 1);
+    const int r = D * h, cc = D * g * L, nn = std::min(r, cc);
+    const size_t bsize = (size_t)h * D * D * g * L;
+    if (bsize > c->bmax || m > c->Mmax)
+      return fail(TNML_ERR_ARG, "step at sites (%d,%d) exceeds the buffers sized for M = %d", p, p + 1, c->Mmax);
+    if ((size_t)h * D * m > c->core_stride || (size_t)m * D * g * L > c->lab_elems)
+      return fail(TNML_ERR_ARG, "new cores at sites (%d,%d) exceed the buffers sized for M = %d", p, p + 1, c->Mmax);
+    if (nn > 64) return fail(TNML_ERR_ARG, "min(rows, cols) = %d > 64: this build's in-LDS Jacobi handles n <= 64", nn);
+    const size_t lds = narrow_lds_bytes(h, g, s, L, m);
+    if (lds > 160 * 1024) return fail(TNML_ERR_ARG, "merged tensor needs %zu B of LDS (> 160 KiB)", lds);
+
+    // ---- wide kernel -----------------------------------------------------------------------
+    WideParams w{};
+    w.b = c->b; w.b_pad = c->b_pad; w.L = L;
+    w.h = h; w.g = g;
+    w.act_fn = act_fn; w.loss_fn = loss_fn; w.T = T;
+    w.y = c->y; w.f = c->f;
+    w.slabs = c->slabs; w.slab_stride = c->slab_stride; w.bsize = (int)bsize;
+    w.x_k = c->X + (size_t)sb * c->b_pad * D;
+    w.x_kp1 = c->X + (size_t)sa * c->b_pad * D;
+    w.hp = 1; w.gp = 1;
+    w.do_ext = (k >= 1);
+    w.first_ext = (k == 1);
+    if (k >= 1) {
+      const int e_site = left_dir ? p + 2 : p - 1;          // site t = k-1, plain since the previous step
+      const int hp = left_dir ? c->mr(e_site) : c->ml(e_site);
+      w.hp = hp;
+      w.x_km1 = c->X + (size_t)e_site * c->b_pad * D;
+      w.ext_core.base = c->core_slot(e_site);
+      w.ext_core.n_in = hp; w.ext_core.n_out = h;
+      if (!left_dir) { w.ext_core.s_in = D * h; w.ext_core.s_d = h; w.ext_core.s_out = 1; }
+      else { w.ext_core.s_in = 1; w.ext_core.s_d = hp; w.ext_core.s_out = D * hp; }
+      w.Hprev = (k >= 2) ? c->env_slot(beh, left_dir ? p + 3 : p - 2) : nullptr;
+      w.Hcur = c->env_slot(beh, left_dir ? p + 2 : p - 1);
+    }
+    if (c->Bnew_valid && !c->f_current) {
+      // f of the previous step from its updated B: that step acted on sites t = k-1, k
+      if (k < 1 || c->prev_h != w.hp || c->prev_g != s)
+        return fail(TNML_ERR_STATE, "internal: previous-step dims (%d,%d) do not match (%d,%d)", c->prev_h, c->prev_g, w.hp, s);
+      w.do_f = 1;
+      w.gp = s;
+      w.Gprev = c->env_slot(ahe, left_dir ? p : p + 1);     // sites t > k
+      w.Bprev = c->Bnew;
+    }
+    {
+      const int gs = left_dir ? p - 1 : p + 2;
+      w.Gcur = (gs >= 0 && gs <= N - 1) ? c->env_slot(ahe, gs) : nullptr;
+    }
+    prof_begin(c);
+    launch_wide(w, nblk, c->stream);
+    prof_end(c, 1);
+    // ---- reduce (+ all-reduce over the batch shards) -----------------------------------------
+    prof_begin(c);
+    launch_reduce(c->slabs, nblk, c->slab_stride, (int)bsize + kMetricSlots, c->red, c->stream);
+    prof_end(c, 2);
+    if (c->comm) NCCL_TRY(ncclAllReduce(c->red, c->red, bsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
+    // ---- narrow kernel -----------------------------------------------------------------------
+    NarrowParams n{};
+    n.L = L; n.D = D; n.h = h; n.g = g; n.s = s; n.m = m; n.bsize = (int)bsize;
+    n.l2_flag = l2_flag ? 1 : 0; n.lr = lr; n.wd = weight_dec;
+    n.red = c->red;
+    n.lab.base = c->lab[c->lab_cur]; n.lab.n_in = h; n.lab.n_out = s;
+    n.pl.base = c->core_slot(sa); n.pl.n_in = s; n.pl.n_out = g;
+    if (!left_dir) {
+      n.lab.s_in = D * s * L; n.lab.s_d = s * L; n.lab.s_out = L;
+      n.pl.s_in = D * g; n.pl.s_d = g; n.pl.s_out = 1;
+      n.ob_s_h = D * m; n.ob_s_d = m; n.ob_s_m = 1;
+      n.oa_s_m = D * g * L; n.oa_s_d = g * L; n.oa_s_g = L;
+    } else {
+      n.lab.s_in = L; n.lab.s_d = h * L; n.lab.s_out = D * h * L;
+      n.pl.s_in = 1; n.pl.s_d = s; n.pl.s_out = D * s;
+      n.ob_s_h = 1; n.ob_s_d = h; n.ob_s_m = D * h;
+      n.oa_s_m = L; n.oa_s_d = m * L; n.oa_s_g = D * m * L;
+    }
+    {
+      const int bs_ = left_dir ? p + 2 : p - 1;     // norm env behind: sites t < k
+      const int as_ = left_dir ? p - 1 : p + 2;     // norm env ahead:  sites t > k+1
+      n.Nh = (l2_flag && bs_ >= 0 && bs_ <= N - 1) ? c->norm_slot(nbeh, bs_) : nullptr;
+      n.Ng = (l2_flag && as_ >= 0 && as_ <= N - 1) ? c->norm_slot(nahe, as_) : nullptr;
+      n.Nh_new = l2_flag ? c->norm_slot(nbeh, sb) : nullptr;
+    }
+    n.Bnew = c->Bnew;
+    n.out_behind = c->core_slot(sb);
+    n.out_ahead = c->lab[c->lab_cur ^ 1];
+    n.metrics = c->metrics + 2 * (size_t)step;
+    n.dbg = c->debug ? c->dbg : nullptr;
+    n.status = c->status;
+    prof_begin(c);
+    launch_narrow(n, lds, c->stream);
+    prof_end(c, 3);
+    // ---- bookkeeping ---------------------------------------------------------------------------
+    c->bond[p] = m;
+    c->l_pos = sa;
+    c->lab_cur ^= 1;
+    c->prev_h = h; c->prev_g = g; c->prev_p = p; c->prev_left_dir = left_dir;
+    c->Bnew_valid = true;
+    c->f_current = false;
+    c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
+  }
+  HIP_TRY(hipGetLastError());
+  // the sweep grew the behind stacks: they are the ones valid for the opposite direction now
+  if (!l2_flag) {
+    c->Ln_valid = c->Rn_valid = false;
+  } else if (c->l_pos == (left_dir ? 0 : N - 1)) {          // sweep complete
+    if (left_dir) { c->Rn_valid = true; c->Ln_valid = false; } else { c->Ln_valid = true; c->Rn_valid = false; }
+  } else {                                                   // mid-sweep: the ahead stack stays usable
+    if (left_dir) c->Rn_valid = false; else c->Ln_valid = false;
+  }
+  // f from the last updated B (the value sweep_step returns, Network_class.py:573)
+  {
+    WideParams w{};
+    w.b = c->b; w.b_pad = c->b_pad; w.L = L;
+    fill_prev_operands(c, w, left_dir, c->prev_p);
+    w.f = c->f;
+    prof_begin(c);
+    launch_f_only(w, nblk, c->stream);
+    prof_end(c, 1);
+    HIP_TRY(hipGetLastError());
+    c->f_current = true;
+  }
+  if (metrics_out) {
+    HIP_TRY(hipMemcpyAsync(metrics_out, c->metrics, (size_t)n_steps * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (f_out) { int rc = copy_f_out(c, c->f, f_out); if (rc) return rc; }
+  if (metrics_out || f_out) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int st = 0;
+    HIP_TRY(hipMemcpy(&st, c->status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+      HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
+      if (st & 1) return fail(TNML_ERR_NONFINITE, "non-finite values reached the bond update / SVD (status %d)", st);
+      return fail(TNML_ERR_NONFINITE, "Jacobi SVD did not converge (status %d)", st);
+    }
+  }
+  return TNML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// inspection
+// ---------------------------------------------------------------------------------------------
+extern "C" int tnml_l_pos(tnml_ctx *c) { return c ? c->l_pos : TNML_ERR_ARG; }
+extern "C" int tnml_batch(tnml_ctx *c) { return c ? c->b : TNML_ERR_ARG; }
+
+extern "C" int tnml_get_env(tnml_ctx *c, int side, int site, float *out, size_t capacity, int *m_out) {
+  if (!c || !out) return fail(TNML_ERR_ARG, "NULL argument");
+  if (site < 0 || site >= c->N) return fail(TNML_ERR_ARG, "site out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  const int m = side == TNML_SIDE_LEFT ? c->mr(site) : c->ml(site);
+  if (capacity < (size_t)m * c->b) return fail(TNML_ERR_ARG, "capacity too small");
+  std::vector<float> tmp((size_t)m * c->b_pad);
+  const float *src = c->env_slot(side == TNML_SIDE_LEFT ? c->Lenv : c->Renv, site);
+  HIP_TRY(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int s = 0; s < c->b; ++s)
+    for (int a = 0; a < m; ++a) out[(size_t)s * m + a] = tmp[(size_t)a * c->b_pad + s];
+  if (m_out) *m_out = m;
+  return TNML_OK;
+}
+
+extern "C" int tnml_debug_enable(tnml_ctx *c, int on) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  c->debug = on != 0;
+  return TNML_OK;
+}
+
+extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t capacity, size_t *n_out) {
+  if (!c || !out) return fail(TNML_ERR_ARG, "NULL argument");
+  if (!c->debug) return fail(TNML_ERR_STATE, "debug capture is off (tnml_debug_enable)");
+  if (c->last_bsize <= 0) return fail(TNML_ERR_STATE, "no step has run yet");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t Bs = c->last_bsize;
+  std::vector<double> hbuf(4 * Bs + 64 + 16);
+  HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, hbuf.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  auto tensor_out = [&](size_t block) -> int {
+    if (capacity < Bs) return fail(TNML_ERR_ARG, "capacity too small");
+    const int D = c->D, L = c->L, h = c->last_h, g = c->last_g;
+    const double *src = hbuf.data() + block * Bs;
+    if (!c->last_left_dir) {
+      memcpy(out, src, Bs * sizeof(double));           // relative == canonical for a right sweep
+    } else {
+      // relative (h, dk, dk1, g, l) -> canonical (a = g, d = dk1, d' = dk, c = h, l)
+      for (int h_ = 0; h_ < h; ++h_) for (int dk = 0; dk < D; ++dk) for (int dk1 = 0; dk1 < D; ++dk1)
+        for (int g_ = 0; g_ < g; ++g_) for (int l = 0; l < L; ++l)
+          out[((((size_t)g_ * D + dk1) * D + dk) * h + h_) * L + l] = src[((((size_t)h_ * D + dk) * D + dk1) * g + g_) * L + l];
+    }
+    if (n_out) *n_out = Bs;
+    return TNML_OK;
+  };
+  switch (what) {
+    case TNML_DBG_B: return tensor_out(0);
+    case TNML_DBG_DB_RAW: return tensor_out(1);
+    case TNML_DBG_B_NEW: return tensor_out(2);
+    case TNML_DBG_L2_GRAD: return tensor_out(3);
+    case TNML_DBG_SIGMA:
+      if (capacity < (size_t)c->last_n) return fail(TNML_ERR_ARG, "capacity too small");
+      memcpy(out, hbuf.data() + 4 * Bs, c->last_n * sizeof(double));
+      if (n_out) *n_out = c->last_n;
+      return TNML_OK;
+    case TNML_DBG_L2:
+      if (capacity < 5) return fail(TNML_ERR_ARG, "capacity too small");
+      memcpy(out, hbuf.data() + 4 * Bs + 64, 5 * sizeof(double));
+      if (n_out) *n_out = 5;
+      return TNML_OK;
+  }
+  return fail(TNML_ERR_ARG, "unknown debug selector %d", what);
+}
+
+// ---------------------------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------------------------
+extern "C" int tnml_timer_start(tnml_ctx *c) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  return TNML_OK;
+}
+extern "C" int tnml_timer_stop(tnml_ctx *c, double *elapsed_ms) {
+  if (!c || !elapsed_ms) return fail(TNML_ERR_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *elapsed_ms = ms;
+  return TNML_OK;
+}
+extern "C" int tnml_profile_enable(tnml_ctx *c, int on) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  c->profile = on != 0;
+  return TNML_OK;
+}
+extern "C" int tnml_profile_get(tnml_ctx *c, int which, double *ms, long long *launches) {
+  if (!c || which < 0 || which > 3) return fail(TNML_ERR_ARG, "bad argument");
+  if (ms) *ms = c->prof_ms[which];
+  if (launches) *launches = c->prof_n[which];
+  return TNML_OK;
+}
+extern "C" int tnml_profile_reset(tnml_ctx *c) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  for (int i = 0; i < 4; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  return TNML_OK;
+}

@@ -1,0 +1,107 @@
+// Internal declarations shared by the translation units of libtnml_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tnml.h"
+
+namespace tnml {
+
+constexpr int kD = 2;           // feature dimension the kernels are specialised for
+constexpr int kTS = 32;         // samples per workgroup in the wide step kernel (v1)
+constexpr int kWideThreads = 256;
+constexpr int kNarrowThreads = 1024;
+constexpr int kMetricSlots = 4; // per-slab tail: correct count, sum|y-fa|, non-finite count, pad
+
+// A plain (label-free) core or the label core addressed in the sweep-relative frame.
+//   plain:  A(in, d, out)      = base[in*s_in + d*s_d + out*s_out]
+//   label:  A(h, d, s, l)      = base[h*s_in + d*s_d + s*s_out + l]   (label stride is 1)
+struct CoreView {
+  const float *base;
+  int n_in, n_out;
+  int s_in, s_d, s_out;
+};
+
+// One site of the forward environment chain (see env_chain_kernel).
+struct ChainSite {
+  int core_off;     // float offset of the core (into cores[] or the label core when is_label)
+  int is_label;
+  int n_in, n_out;  // n_in = dimension of the incoming environment, n_out of the produced one
+  int s_in, s_d, s_out;
+  int x_site;       // absolute site whose features are contracted
+  long long env_out_off;  // float offset of the produced environment slot, -1 for the label site
+};
+
+// Everything the wide step kernel needs, in the sweep-relative frame.
+struct WideParams {
+  int b, b_pad, L;
+  int h, g;            // behind / ahead bond of the merged tensor of THIS step
+  int hp, gp;          // the same for the previous step (f part); gp == shared bond of this step
+  int do_f;            // recompute f from the previous step's updated B
+  int do_ext;          // behind environment has to be extended (k >= 1)
+  int first_ext;       // extension starts from the scalar 1 (k == 1)
+  int act_fn, loss_fn;
+  float T;
+  const float *x_km1, *x_k, *x_kp1;   // [b_pad][D]
+  const float *Hprev;  // behind env of the previous step  [hp][b_pad]
+  float *Hcur;         // behind env of this step          [h][b_pad]  (written when do_ext)
+  const float *Gprev;  // ahead env of the previous step   [gp][b_pad]
+  const float *Gcur;   // ahead env of this step           [g][b_pad]
+  const float *Bprev;  // updated merged tensor of the previous step, relative layout
+  CoreView ext_core;   // core of site t=k-1: A(hp, d, h)
+  const int *y;        // [b_pad]
+  float *f;            // [L][b_pad]   read (do_f == 0) or written (do_f == 1)
+  float *slabs;        // [nblk][slab_stride]
+  int slab_stride;
+  int bsize;           // h*D*D*g*L
+};
+
+struct NarrowParams {
+  int L, D;
+  int h, g, s, m;          // behind, ahead, shared bond before the step; kept rank m
+  int bsize;               // h*D*D*g*L
+  int l2_flag;
+  float lr, wd;
+  double inv_b_global;     // 1 / global batch
+  const float *red;        // reduced slab: dB_raw (relative layout) + metric tail
+  CoreView lab;            // label core of site t=k:   A(h, d, s, l)
+  CoreView pl;             // plain core of site t=k+1: A(s, d, g)
+  const double *Nh;        // behind norm env (h x h) or nullptr (== [[1]])
+  const double *Ng;        // ahead  norm env (g x g) or nullptr
+  float *Bnew;             // out: updated merged tensor, relative layout
+  float *out_behind;       // out: new plain core of site t=k
+  int ob_s_h, ob_s_d, ob_s_m;          // strides of (h, d, s') in out_behind
+  float *out_ahead;        // out: new label core of site t=k+1
+  int oa_s_m, oa_s_d, oa_s_g;          // strides of (s', d, g) in out_ahead (label stride 1)
+  double *Nh_new;          // out: behind norm env of the next step (m x m)
+  float *metrics;          // out: (accuracy, MAE) of this step
+  double *dbg;             // debug block (see narrow kernel), may be nullptr
+  int *status;             // device status word: bit0 non-finite, bit1 jacobi not converged
+};
+
+struct NormChainSite {
+  int core_off;
+  int n_in, n_out, s_in, s_d, s_out;   // A(in, d, out): env over `in` -> env over `out`
+  long long env_out_off;               // double offset of the produced norm environment
+};
+
+void launch_transpose_input(const float *X_bnd, float *X_nbd, int b, int b_pad, int N, hipStream_t st);
+void launch_env_chain(const ChainSite *sites_dev, int n_sites, const float *cores, const float *labcore,
+                      const float *X, float *env_base, float *f, int b, int b_pad, int L, int Mmax,
+                      hipStream_t st);
+void launch_wide(const WideParams &p, int nblk, hipStream_t st);
+void launch_f_only(const WideParams &p, int nblk, hipStream_t st);
+void launch_reduce(const float *slabs, int nblk, int slab_stride, int n, float *red, hipStream_t st);
+void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st);
+size_t narrow_lds_bytes(int h, int g, int s, int L, int m);
+void launch_norm_chain(const NormChainSite *sites_dev, int n_sites, const float *cores, double *env_base,
+                       int Mmax, hipStream_t st);
+void launch_scale(float *p, size_t n, float factor, hipStream_t st);
+void launch_absmax(const float *f, int L, int b, int b_pad, float *out, hipStream_t st);
+void launch_activation(const float *f, const int *y, int L, int b, int b_pad, int act_fn, int loss_fn,
+                       float T, float *act_out, float *der_out, hipStream_t st);
+
+}  // namespace tnml
