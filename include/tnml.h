@@ -95,6 +95,9 @@ int tnml_scale_cores(tnml_ctx *ctx, double factor);
 /* ---- batch ------------------------------------------------------------------------------ */
 /* X [b][N][D] float32, y [b] int32 (may be NULL when only forward is wanted) */
 int tnml_set_input(tnml_ctx *ctx, const float *X, const int32_t *y, int b);
+/* labels of the resident batch alone (Network.sweep receives y after forward saw X,
+ * Network_class.py:327-333) */
+int tnml_set_labels(tnml_ctx *ctx, const int32_t *y, int b);
 
 /* ---- hot path --------------------------------------------------------------------------- */
 /* Network.forward (Network_class.py:195-258): builds the environment stack for the current
@@ -102,6 +105,11 @@ int tnml_set_input(tnml_ctx *ctx, const float *X, const int32_t *y, int b);
 int tnml_forward(tnml_ctx *ctx, float *f_out);
 /* max |f| over the (global) batch after a forward: Network_class.py:169 */
 int tnml_f_absmax(tnml_ctx *ctx, double *out);
+/* log(max |f|) over the (global) batch with per-site renormalisation: the calibration of
+ * Network.__init__ (Network_class.py:168-170) needs max|f| of the un-calibrated chain, which is
+ * ~1e-66 at N = 784 and underflows float32; this variant is exact in any range and leaves the
+ * environment stacks untouched. */
+int tnml_forward_logabsmax(tnml_ctx *ctx, double *out);
 /* the f the next sweep step starts from (Network.sweep's argument f, Network_class.py:384) */
 int tnml_set_f(tnml_ctx *ctx, const float *f);
 int tnml_get_f(tnml_ctx *ctx, float *f_out);
@@ -118,9 +126,10 @@ int tnml_sweep(tnml_ctx *ctx, int left_dir, int n_steps, int first_of_sweep, flo
                float *metrics_out, float *f_out);
 
 /* Network.apply_act_func / compute_loss_derivate on the device-resident f (:767-835);
- * act_out, lossder_out [L][b], either may be NULL */
-int tnml_activation(tnml_ctx *ctx, int act_fn, int loss_fn, float T, float *act_out,
-                    float *lossder_out);
+ * act_out, lossder_out [L][b], either may be NULL.  input_is_activated != 0: f already went
+ * through the activation (what compute_loss_derivate receives, :800), only the derivative runs. */
+int tnml_activation(tnml_ctx *ctx, int act_fn, int loss_fn, float T, int input_is_activated,
+                    float *act_out, float *lossder_out);
 
 /* ---- inspection (API parity: Network.r_cum_contraction / l_cum_contraction) -------------- */
 int tnml_get_env(tnml_ctx *ctx, int side, int site, float *out, size_t capacity, int *m);

@@ -22,7 +22,7 @@ DBG = {'B': 0, 'dB_raw': 1, 'B_new': 2, 'sigma': 3, 'scalars': 4, 'L2_grad': 5}
 SYMBOLS = [
     'tnml_last_error', 'tnml_version', 'tnml_device_count', 'tnml_create', 'tnml_destroy',
     'tnml_synchronize', 'tnml_comm_unique_id', 'tnml_comm_init', 'tnml_set_cores', 'tnml_cores_size',
-    'tnml_get_cores', 'tnml_scale_cores', 'tnml_set_input', 'tnml_forward', 'tnml_f_absmax',
+    'tnml_get_cores', 'tnml_scale_cores', 'tnml_set_input', 'tnml_set_labels', 'tnml_forward', 'tnml_forward_logabsmax', 'tnml_f_absmax',
     'tnml_set_f', 'tnml_get_f', 'tnml_sweep', 'tnml_activation', 'tnml_get_env', 'tnml_debug_enable',
     'tnml_get_step_debug', 'tnml_l_pos', 'tnml_batch', 'tnml_timer_start', 'tnml_timer_stop',
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_trunc_rank',
@@ -61,13 +61,15 @@ def lib():
         L.tnml_get_cores.argtypes = [vp, f32p, C.c_size_t, i32p, C.POINTER(C.c_int)]
         L.tnml_scale_cores.argtypes = [vp, C.c_double]
         L.tnml_set_input.argtypes = [vp, f32p, i32p, C.c_int]
+        L.tnml_set_labels.argtypes = [vp, i32p, C.c_int]
         L.tnml_forward.argtypes = [vp, f32p]
         L.tnml_f_absmax.argtypes = [vp, f64p]
+        L.tnml_forward_logabsmax.argtypes = [vp, f64p]
         L.tnml_set_f.argtypes = [vp, f32p]
         L.tnml_get_f.argtypes = [vp, f32p]
         L.tnml_sweep.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                  C.c_int, C.c_float, C.c_int, f32p, f32p]
-        L.tnml_activation.argtypes = [vp, C.c_int, C.c_int, C.c_float, f32p, f32p]
+        L.tnml_activation.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int, f32p, f32p]
         L.tnml_get_env.argtypes = [vp, C.c_int, C.c_int, f32p, C.c_size_t, C.POINTER(C.c_int)]
         L.tnml_debug_enable.argtypes = [vp, C.c_int]
         L.tnml_get_step_debug.argtypes = [vp, C.c_int, f64p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -182,6 +184,10 @@ class Context:
         _chk(lib().tnml_set_input(self._h, _ptr(X, C.c_float), yp, X.shape[0]))
         self.b = X.shape[0]
 
+    def set_labels(self, y):
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        _chk(lib().tnml_set_labels(self._h, _ptr(y, C.c_int32), y.shape[0]))
+
     # ---- hot path
     def forward(self, want_f=True):
         if not want_f:
@@ -190,6 +196,12 @@ class Context:
         f = np.empty((self.L, self.b), dtype=np.float32)
         _chk(lib().tnml_forward(self._h, _ptr(f, C.c_float)))
         return f
+
+    def forward_logabsmax(self):
+        """log max|f| of the resident batch, exact even where f under/overflows float32."""
+        v = C.c_double()
+        _chk(lib().tnml_forward_logabsmax(self._h, C.byref(v)))
+        return v.value
 
     def f_absmax(self):
         v = C.c_double()
@@ -216,13 +228,16 @@ class Context:
                               _ptr(f, C.c_float) if want_f else None))
         return met, f
 
-    def activation(self, act_fn, loss_fn, T, want_act=True, want_der=False):
+    def activation(self, act_fn, loss_fn, T, want_act=True, want_der=False, input_is_activated=False):
         a = np.empty((self.L, self.b), dtype=np.float32) if want_act else None
         d = np.empty((self.L, self.b), dtype=np.float32) if want_der else None
-        _chk(lib().tnml_activation(self._h, ACT[act_fn], LOSS[loss_fn], float(T),
+        _chk(lib().tnml_activation(self._h, ACT[act_fn], LOSS[loss_fn], float(T), int(bool(input_is_activated)),
                                    _ptr(a, C.c_float) if want_act else None,
                                    _ptr(d, C.c_float) if want_der else None))
         return a, d
+
+    def loss_derivative_of_activated(self, act_fn, loss_fn, T):
+        return self.activation(act_fn, loss_fn, T, want_act=False, want_der=True, input_is_activated=True)[1]
 
     # ---- inspection
     def get_env(self, side, site):

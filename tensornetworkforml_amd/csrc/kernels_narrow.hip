@@ -9,24 +9,54 @@
 // reach 1e196, and the SVD goes through the Gram matrix, whose float64 accumulation
 // keeps the squared condition number harmless for float32 data.
 //
-// SVD method: G = W^T W (n x n, n = min(rows, cols) <= 64) in float64, then one-sided (Hestenes)
-// Jacobi on the columns of [G; I] with a round-robin pair schedule: n/2 pairs rotate concurrently,
-// 32 lanes per pair, one barrier per round.  Columns of the bottom half converge to the
-// eigenvectors q_j of G, top-half column norms to the eigenvalues sigma_j^2.  The short-side factor
-// is q_j sqrt(sigma_j), the long-side one W q_j / sqrt(sigma_j), so that their product is the
+// SVD method: G = W^T W (n x n, n = min(rows, cols) <= 64) accumulated in float64, then the classical
+// two-sided Jacobi eigenvalue iteration G <- J^T G J, V <- V J with a round-robin pair schedule:
+// n/2 disjoint rotations per round.  A thread owns one 2x2 block G[{p1,p2},{q1,q2}] (or V[{2r,2r+1},
+// {q1,q2}]) of the current pairing and applies both rotations to it, reading the old matrix and
+// writing the new one into a second LDS buffer, so a round costs one barrier and no reduction.  The
+// rotation angle comes from a float evaluation of t = 2g / (d + sign(d) sqrt(d^2 + 4 g^2)); c is
+// then refined to float64 (one Newton step on rsqrt) so that c^2 + s^2 = 1 to 1e-14 and V stays
+// orthogonal.  Eigenvalues sigma_j^2 = diag(G), eigenvectors q_j = columns of V.  The short-side
+// factor is q_j sqrt(sigma_j), the long-side one W q_j / sqrt(sigma_j), so that their product is the
 // projection W Q Q^T whatever the accuracy of the small sigma_j.
 #include "tnml_internal.h"
 
 namespace tnml {
 
-__device__ inline double group32_sum(double v) {
-  // all-reduce inside an aligned group of 32 lanes
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
-  return v;
+// Rotation (c, s) that annihilates g in [[a, g], [g, b]] under J = [[c, s], [-s, c]] (columns:
+// a' = c a - s b, b' = s a + c b).  level: 0 negligible (identity), 1 small, 2 large -- the sweep
+// loop stops once a whole sweep made only small rotations (quadratic convergence then leaves
+// off-diagonals below the tolerance).
+// Convergence thresholds of the Jacobi iteration, all on g^2 / scale2 with
+//   scale2 = max(a b, (kKeptFrac * lambda_m)^2),   lambda_m = m-th largest diagonal entry:
+// diagonal entries far below the smallest eigenvalue that is KEPT are treated as if they were at
+// that level, i.e. the discarded cluster is not resolved to high relative accuracy (it only has to
+// be separated from the kept subspace).  Emulated on headline-shaped matrices: 7.5 sweeps instead
+// of 9.4, truncated product within 2e-8 of LAPACK's (tools/jacobi_emulation.py).
+constexpr double kJacobiTol2 = 1e-14;     // below: pair left alone
+constexpr double kJacobiBig2 = 1e-4;      // above: "big" rotation; a sweep without one ends the iteration
+constexpr double kKeptFrac = 0.2;
+constexpr double kJacobiAbs = 1e-15;      // |g| / trace floor: eigenvalues under 1e-15 trace are float32 noise of B
+
+// Rotation J = [[c, s], [-s, c]] annihilating g in [[a, g], [g, b]] (columns: a' = c a - s b,
+// b' = s a + c b); t = s / c.  G is pre-scaled to trace ~ 1, so the float evaluation of
+// t = 2g / (d + sign(d) sqrt(d^2 + 4 g^2)) can neither overflow nor (above the floor) underflow;
+// c is refined to float64 by one Newton step on rsqrt so that c^2 + s^2 = 1 to ~1e-14.
+struct Rot { double c, s, t; int level; };
+__device__ inline Rot jacobi_rot(double a, double b, double g, double kept2, double abs2) {
+  Rot r; r.c = 1.0; r.s = 0.0; r.t = 0.0; r.level = 0;
+  const double g2 = g * g;
+  const double sc = fmax(fabs(a * b), kept2);
+  const bool act = g2 > fmax(kJacobiTol2 * sc, abs2);          // false for g == 0 and NaN
+  const float df = (float)(b - a), gf = (float)g;
+  const float hyp = __builtin_amdgcn_sqrtf(fmaf(df, df, 4.f * gf * gf));
+  const float t = 2.f * gf * __builtin_amdgcn_rcpf(df + copysignf(hyp, df));
+  const double td = (double)t;
+  const double x = fma(td, td, 1.0);                           // in [1, 2]
+  double c0 = (double)__builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
+  c0 = c0 * fma(-0.5 * x, c0 * c0, 1.5);
+  if (act) { r.c = c0; r.s = c0 * td; r.t = td; r.level = (g2 > kJacobiBig2 * sc) ? 2 : 1; }
+  return r;
 }
 
 // block-wide sum of up to 3 doubles; result valid in every thread.  scratch: >= 3*16 doubles.
@@ -46,9 +76,9 @@ __device__ inline void block_sum3(double &a, double &b, double &c, double *scrat
 }
 
 struct NarrowCarve {
-  double *dT, *dG, *Z, *dNh, *dNg, *dLam, *dRed, *dT2;
+  double *dT, *dG, *Z, *dNh, *dNg, *dLam, *dRed, *dT2, *dCS;
   float *fB, *sLab, *sPl, *sCb;
-  int *sOrd, *sFlag;
+  int *sOrd, *sFlag, *sPi, *sPiInv;
   size_t bytes;
 };
 
@@ -58,15 +88,16 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
   const int r = D * h, c = D * g * L;
   const int n = r <= c ? r : c, ne = n + (n & 1);
   size_t zreg = 2 * Bs;
-  if ((size_t)2 * n * ne > zreg) zreg = (size_t)2 * n * ne;
+  if ((size_t)4 * ne * ne > zreg) zreg = (size_t)4 * ne * ne;   // G and V, two buffers each, ne x ne
   NarrowCarve k;
   double *d = (double *)base;
   k.dT = d; k.dG = d + Bs; k.Z = d; d += zreg;
-  k.dNh = d; d += (size_t)h * h;
-  k.dNg = d; d += (size_t)g * g;
+  k.dNh = d; d += ((size_t)h * h + 1) & ~(size_t)1;
+  k.dNg = d; d += ((size_t)g * g + 1) & ~(size_t)1;
   k.dLam = d; d += ne;
   k.dRed = d; d += 64;
   k.dT2 = d; d += (size_t)h * D * m;
+  k.dCS = d; d += 4 * ne;                   // (c, s, t, -) per pair, two rounds in flight
   float *f = (float *)d;
   k.fB = f; f += Bs;
   k.sLab = f; f += (size_t)h * D * s * L;
@@ -75,6 +106,8 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
   int *ip = (int *)f;
   k.sOrd = ip; ip += ne;
   k.sFlag = ip; ip += 4;
+  k.sPi = ip; ip += ne;
+  k.sPiInv = ip; ip += ne;
   k.bytes = (size_t)((unsigned char *)ip - base);
   return k;
 }
@@ -83,7 +116,6 @@ size_t narrow_lds_bytes(int h, int g, int s, int L, int m) {
   return narrow_carve(nullptr, h, g, s, L, m).bytes + 16;
 }
 
-constexpr double kJacobiTol = 1e-11;
 constexpr int kJacobiMaxSweeps = 30;
 
 __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParams p) {
@@ -94,7 +126,6 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   const int r = D * h, c = D * g * L;
   const bool short_rows = (r <= c);
   const int n = short_rows ? r : c, ne = n + (n & 1), len = short_rows ? c : r;
-  const int twoN = 2 * n;
 
   // ---- phase 0: stage the two cores and the norm environments ---------------------------------
   for (int e = tid; e < h * D * s * L; e += NT) {
@@ -188,78 +219,168 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   }
   __syncthreads();   // dT/dG are dead from here on; Z aliases them
 
-  // ---- phase 6: Gram matrix in float64 -> top half of Z, identity -> bottom half ----------------
+  // ---- phase 6: Gram matrix in float64 (padded to ne x ne with a zero row/column), V = I ----------
   //   W(x, kk) = short_rows ? Bm[kk][x] : Bm[x][kk]   with Bm = B_new as (r x c) row-major
-  for (int e = tid; e < n * n; e += NT) {
-    const int col = e / n, kk = e % n;
+  double *G0 = k.Z, *G1 = k.Z + ne * ne, *V0 = k.Z + 2 * ne * ne, *V1 = k.Z + 3 * ne * ne;
+  for (int e = tid; e < ne * ne; e += NT) {
+    const int col = e / ne, kk = e % ne;
     double acc = 0.0;
-    if (short_rows) {
-      const float *ra = k.fB + (size_t)kk * c, *rb = k.fB + (size_t)col * c;
-      for (int x = 0; x < len; ++x) acc += (double)ra[x] * (double)rb[x];
-    } else {
-      for (int x = 0; x < len; ++x) acc += (double)k.fB[(size_t)x * c + kk] * (double)k.fB[(size_t)x * c + col];
+    if (col < n && kk < n && kk <= col) {
+      if (short_rows) {
+        const float *ra = k.fB + kk * c, *rb = k.fB + col * c;
+        for (int x = 0; x < len; ++x) acc += (double)ra[x] * (double)rb[x];
+      } else {
+        for (int x = 0; x < len; ++x) acc += (double)k.fB[x * c + kk] * (double)k.fB[x * c + col];
+      }
     }
-    k.Z[(size_t)col * twoN + kk] = acc;
-    k.Z[(size_t)col * twoN + n + kk] = (kk == col) ? 1.0 : 0.0;
+    if (kk <= col) { G0[kk * ne + col] = acc; G0[col * ne + kk] = acc; }
+    V0[e] = (kk == col) ? 1.0 : 0.0;
+  }
+  // Tournament in POSITION space: the pairs of a round are always the positions (2k, 2k+1); after
+  // the rotations every row/column moves to position pi(pos) of the next round (circle method:
+  // position 0 fixed, top row shifts right, bottom row shifts left).  The move is free: the updated
+  // blocks are written into the other buffer anyway.
+  const int np = ne / 2;                      // pairs per round
+  for (int pos = tid; pos < ne; pos += NT) {
+    const int kq = pos >> 1;
+    int nxt;
+    if (pos & 1) nxt = (kq == 0) ? (np > 1 ? 2 : 1) : 2 * (kq - 1) + 1;          // bottom row
+    else nxt = (kq == 0) ? 0 : (kq == np - 1 ? 2 * kq + 1 : 2 * (kq + 1));       // top row
+    k.sPi[pos] = nxt;
+    k.sPiInv[nxt] = pos;
   }
   __syncthreads();
+  // scale G to trace ~ 1 by an exact power of two (undone on the eigenvalues in phase 8)
+  double tr = 0.0;
+  for (int j = 0; j < n; ++j) tr += G0[j * ne + j];
+  const int sc_exp = (tr > 0.0 && isfinite(tr)) ? __builtin_amdgcn_frexp_exp(tr) : 0;
+  __syncthreads();
+  for (int e = tid; e < ne * ne; e += NT) G0[e] = __builtin_amdgcn_ldexp(G0[e], -sc_exp);
+  __syncthreads();
 
-  // ---- phase 7: one-sided Jacobi, round-robin schedule, 32 lanes per pair -----------------------
-  const int grp = tid >> 5, lane32 = tid & 31;
+  // ---- phase 7: two-sided Jacobi, ONE barrier per round ----------------------------------------------
+  // Workers (tid >= 64) own one 2x2 block of G and one of V per item: rows by R_P^T, columns by R_Q,
+  // written into the other buffer at the next round's positions.  Meanwhile parameter thread k
+  // (tid < np) prepares the rotation of pair k of the NEXT round: that pair is (a, b) =
+  // (piInv(2k), piInv(2k+1)) in today's positions, its new diagonal follows from today's diagonal
+  // blocks (alpha' = alpha - t gamma, beta' = beta + t gamma) and its new off-diagonal element from
+  // one element of the updated block (A, B), which the thread recomputes itself.
+  constexpr int T0 = 64;
+  const int NW = NT - T0;
   int sweeps = 0, converged = 0;
+  double *Gc = G0, *Gn = G1, *Vc = V0, *Vn = V1;
+  bool itValid[2];
+  int itP[2], itQ[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int it = (tid - T0) + u * NW;
+    itValid[u] = tid >= T0 && it < np * np;
+    itP[u] = it / np;
+    itQ[u] = it - itP[u] * np;
+  }
+  const double abs2 = kJacobiAbs * kJacobiAbs;      // trace is ~1 after scaling
+  // parameter-thread constants
+  const bool isParam = tid < np;
+  int pa = 0, pb = 1;
+  if (isParam) { pa = k.sPiInv[2 * tid]; pb = k.sPiInv[2 * tid + 1]; }
+  const int pA = pa >> 1, ra = pa & 1, pB = pb >> 1, rb = pb & 1;
+
+  auto kept_scale = [&](const double *G) -> double {
+    // (kKeptFrac * m-th largest diagonal entry)^2, block-wide; ends with a barrier
+    for (int j = tid; j < n; j += NT) {
+      const double lj = G[j * ne + j];
+      int rank = 0;
+      for (int i = 0; i < n; ++i) { const double li = G[i * ne + i]; rank += (li > lj) || (li == lj && i < j); }
+      if (rank == m - 1) k.dRed[60] = lj;
+    }
+    __syncthreads();
+    const double lm = kKeptFrac * fmax(k.dRed[60], 0.0);
+    return lm * lm;
+  };
+
+  int cur = 0;
   if (n > 1) {
+    double kept2 = kept_scale(Gc);
+    if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
+    if (isParam) {                                   // rotations of the very first round
+      const double2 top = *reinterpret_cast<const double2 *>(Gc + (2 * tid) * ne + 2 * tid);
+      const Rot r = jacobi_rot(top.x, Gc[(2 * tid + 1) * ne + 2 * tid + 1], top.y, kept2, abs2);
+      double *o = k.dCS + (cur * np + tid) * 4;
+      o[0] = r.c; o[1] = r.s; o[2] = r.t;
+      if (r.level >= 1) k.sFlag[0] = 1;
+      if (r.level >= 2) k.sFlag[1] = 1;
+    }
+    __syncthreads();
     for (; sweeps < kJacobiMaxSweeps; ++sweeps) {
-      if (tid == 0) k.sFlag[0] = 0;
-      __syncthreads();
       for (int rnd = 0; rnd < ne - 1; ++rnd) {
-        int pc, qc;
-        if (grp == 0) { pc = ne - 1; qc = rnd; }
-        else { pc = (rnd + grp) % (ne - 1); qc = (rnd - grp + (ne - 1)) % (ne - 1); }
-        if (grp < ne / 2 && pc < n && qc < n) {
-          double a[4], b[4];
-          double al = 0.0, be = 0.0, ga = 0.0;
+        const double *csc = k.dCS + cur * np * 4;
+        if (isParam) {
+          const double2 csA = *reinterpret_cast<const double2 *>(csc + 4 * pA);
+          const double2 csB = *reinterpret_cast<const double2 *>(csc + 4 * pB);
+          const double tA = csc[4 * pA + 2], tB = csc[4 * pB + 2];
+          const double2 dA = *reinterpret_cast<const double2 *>(Gc + (2 * pA) * ne + 2 * pA);
+          const double bA = Gc[(2 * pA + 1) * ne + 2 * pA + 1];
+          const double2 dB = *reinterpret_cast<const double2 *>(Gc + (2 * pB) * ne + 2 * pB);
+          const double bB = Gc[(2 * pB + 1) * ne + 2 * pB + 1];
+          const double2 r0 = *reinterpret_cast<const double2 *>(Gc + (2 * pA) * ne + 2 * pB);
+          const double2 r1 = *reinterpret_cast<const double2 *>(Gc + (2 * pA + 1) * ne + 2 * pB);
+          const double na = ra ? fma(tA, dA.y, bA) : fma(-tA, dA.y, dA.x);
+          const double nb = rb ? fma(tB, dB.y, bB) : fma(-tB, dB.y, dB.x);
+          // element (ra, rb) of R_A^T . blk . R_B
+          const double h0 = ra ? fma(csA.y, r0.x, csA.x * r1.x) : fma(csA.x, r0.x, -csA.y * r1.x);
+          const double h1 = ra ? fma(csA.y, r0.y, csA.x * r1.y) : fma(csA.x, r0.y, -csA.y * r1.y);
+          const double ng = rb ? fma(csB.y, h0, csB.x * h1) : fma(csB.x, h0, -csB.y * h1);
+          const Rot r = jacobi_rot(na, nb, ng, kept2, abs2);
+          double *o = k.dCS + ((cur ^ 1) * np + tid) * 4;
+          o[0] = r.c; o[1] = r.s; o[2] = r.t;
+          if (r.level >= 1) k.sFlag[0] = 1;
+          if (r.level >= 2) k.sFlag[1] = 1;
+        }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int kk = lane32 + 32 * i;
-            a[i] = 0.0; b[i] = 0.0;
-            if (kk < twoN) {
-              a[i] = k.Z[(size_t)pc * twoN + kk];
-              b[i] = k.Z[(size_t)qc * twoN + kk];
-              if (kk < n) { al += a[i] * a[i]; be += b[i] * b[i]; ga += a[i] * b[i]; }
-            }
-          }
-          al = group32_sum(al); be = group32_sum(be); ga = group32_sum(ga);
-          if (fabs(ga) > kJacobiTol * sqrt(al * be)) {
-            const double zeta = (be - al) / (2.0 * ga);
-            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int kk = lane32 + 32 * i;
-              if (kk < twoN) {
-                k.Z[(size_t)pc * twoN + kk] = cs * a[i] - sn * b[i];
-                k.Z[(size_t)qc * twoN + kk] = sn * a[i] + cs * b[i];
-              }
-            }
-            if (lane32 == 0) k.sFlag[0] = 1;
-          }
+        for (int u = 0; u < 2; ++u) {
+          if (!itValid[u]) continue;
+          const int P = itP[u], Q = itQ[u];
+          const double2 csq = *reinterpret_cast<const double2 *>(csc + 4 * Q);
+          const double2 csp = *reinterpret_cast<const double2 *>(csc + 4 * P);
+          const int c1 = k.sPi[2 * Q], c2 = k.sPi[2 * Q + 1];
+          const int o1 = k.sPi[2 * P], o2 = k.sPi[2 * P + 1];
+          const double2 r0 = *reinterpret_cast<const double2 *>(Gc + (2 * P) * ne + 2 * Q);
+          const double2 r1 = *reinterpret_cast<const double2 *>(Gc + (2 * P + 1) * ne + 2 * Q);
+          const double2 v0 = *reinterpret_cast<const double2 *>(Vc + (2 * P) * ne + 2 * Q);
+          const double2 v1 = *reinterpret_cast<const double2 *>(Vc + (2 * P + 1) * ne + 2 * Q);
+          const double h11 = csp.x * r0.x - csp.y * r1.x, h12 = csp.x * r0.y - csp.y * r1.y;
+          const double h21 = csp.y * r0.x + csp.x * r1.x, h22 = csp.y * r0.y + csp.x * r1.y;
+          double n11 = csq.x * h11 - csq.y * h12, n12 = csq.y * h11 + csq.x * h12;
+          double n21 = csq.x * h21 - csq.y * h22, n22 = csq.y * h21 + csq.x * h22;
+          if (P == Q && csq.y != 0.0) { n12 = 0.0; n21 = 0.0; }   // the annihilated element, exactly
+          Gn[o1 * ne + c1] = n11; Gn[o1 * ne + c2] = n12;
+          Gn[o2 * ne + c1] = n21; Gn[o2 * ne + c2] = n22;
+          // eigenvectors: columns only, rows stay in place
+          Vn[(2 * P) * ne + c1] = csq.x * v0.x - csq.y * v0.y;
+          Vn[(2 * P) * ne + c2] = csq.y * v0.x + csq.x * v0.y;
+          Vn[(2 * P + 1) * ne + c1] = csq.x * v1.x - csq.y * v1.y;
+          Vn[(2 * P + 1) * ne + c2] = csq.y * v1.x + csq.x * v1.y;
         }
         __syncthreads();
+        double *tsw = Gc; Gc = Gn; Gn = tsw;
+        tsw = Vc; Vc = Vn; Vn = tsw;
+        cur ^= 1;
       }
-      const int rotated = k.sFlag[0];
+      // the flags cover the rotations applied in the last ne-2 rounds plus the one prepared for the
+      // next round: any ne-1 consecutive rounds form a complete sweep
+      const int any_rot = k.sFlag[0], big_rot = k.sFlag[1];
       __syncthreads();
-      if (!rotated) { converged = 1; ++sweeps; break; }
+      if (!any_rot || !big_rot) { converged = 1; ++sweeps; break; }
+      if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
+      kept2 = kept_scale(Gc);
     }
   } else {
     converged = 1;
   }
+  double *V = Vc;
 
-  // ---- phase 8: eigenvalues (top-half column norms), descending order ---------------------------
-  for (int j = tid; j < n; j += NT) {
-    double acc = 0.0;
-    for (int kk = 0; kk < n; ++kk) { const double v = k.Z[(size_t)j * twoN + kk]; acc += v * v; }
-    k.dLam[j] = sqrt(acc);
-  }
+  // ---- phase 8: eigenvalues = diag(G), descending order -------------------------------------------
+  for (int j = tid; j < n; j += NT) k.dLam[j] = __builtin_amdgcn_ldexp(fmax(Gc[j * ne + j], 0.0), sc_exp);
   __syncthreads();
   for (int j = tid; j < n; j += NT) {
     const double lj = k.dLam[j];
@@ -289,7 +410,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     const int j = k.sOrd[sp];
     const double lam = k.dLam[j];
     const double sq = (lam > 1e-300 && lam > 1e-30 * lam_max) ? sqrt(sqrt(lam)) : 0.0;
-    const float v = (float)(k.Z[(size_t)j * twoN + n + kk] * sq);
+    const float v = (float)(V[(size_t)kk * ne + j] * sq);
     if (short_rows) {                       // kk = row index i = h_*D + dk  -> behind core
       k.sCb[kk * m + sp] = v;
       p.out_behind[(kk / D) * p.ob_s_h + (kk % D) * p.ob_s_d + sp * p.ob_s_m] = v;
@@ -303,13 +424,13 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     const int sp = e % m, x = e / m;
     const int j = k.sOrd[sp];
     const double lam = k.dLam[j];
-    const double *q = k.Z + (size_t)j * twoN + n;
+    const double *q = V + j;                // q[kk] = V[kk][j], stride ne
     double acc = 0.0;
     if (short_rows) {                       // x = column index, sum over rows
-      for (int kk = 0; kk < n; ++kk) acc += (double)k.fB[(size_t)kk * c + x] * q[kk];
+      for (int kk = 0; kk < n; ++kk) acc += (double)k.fB[(size_t)kk * c + x] * q[(size_t)kk * ne];
     } else {                                // x = row index, sum over columns
       const float *row = k.fB + (size_t)x * c;
-      for (int kk = 0; kk < n; ++kk) acc += (double)row[kk] * q[kk];
+      for (int kk = 0; kk < n; ++kk) acc += (double)row[kk] * q[(size_t)kk * ne];
     }
     const double isq = (lam > 1e-300 && lam > 1e-30 * lam_max) ? 1.0 / sqrt(sqrt(lam)) : 0.0;
     const float v = (float)(acc * isq);

@@ -47,23 +47,31 @@ void launch_transpose_input(const float *X_bnd, float *X_nbd, int b, int b_pad, 
 constexpr int kChainTS = 16;
 constexpr int kChainThreads = 512;
 
+// LOGMODE (calibration, Network_class.py:168-170): the running environment of every sample is
+// renormalised by its max |.| after each site and the logs are accumulated, so that chains whose
+// output under- or overflows float32 (1e-66 for the un-calibrated 784-site chain) still yield
+// log max|f| exactly.  Nothing is written to the environment stack in this mode; the per-workgroup
+// maxima of log|f| go to logmax_out[blockIdx.x].
+template <bool LOGMODE>
 __global__ __launch_bounds__(kChainThreads) void env_chain_kernel(
     const ChainSite *__restrict__ sites, int n_sites, const float *__restrict__ cores,
     const float *__restrict__ labcore, const float *__restrict__ X, float *__restrict__ env_base,
-    float *__restrict__ f, int b, int b_pad, int L, int Mmax) {
+    float *__restrict__ f, int b, int b_pad, int L, int Mmax, float *__restrict__ logmax_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int mo = Mmax > L ? Mmax : L;
   float *sA = smem;                               // [n_in][D][n_out]
   float *sE0 = sA + (size_t)Mmax * kD * mo;       // [Mmax][TS]
   float *sE1 = sE0 + (size_t)mo * kChainTS;
   float *sX = sE1 + (size_t)mo * kChainTS;        // [TS][D]
+  float *sScale = sX + kChainTS * kD;             // [TS] accumulated log scale   (LOGMODE)
+  unsigned *sMax = (unsigned *)(sScale + kChainTS);  // [TS] max |v| of the site, as float bits
   const int tid = threadIdx.x;
   const int sl = tid % kChainTS, og = tid / kChainTS;
   constexpr int OG = kChainThreads / kChainTS;
   const int s = blockIdx.x * kChainTS + sl;
 
   float *cur = sE0, *nxt = sE1;
-  if (tid < kChainTS) cur[tid] = 1.0f;
+  if (tid < kChainTS) { cur[tid] = 1.0f; sScale[tid] = 0.f; sMax[tid] = 0u; }
   for (int i = 0; i < n_sites; ++i) {
     const ChainSite cs = sites[i];
     const float *src = (cs.is_label ? labcore : cores) + cs.core_off;
@@ -88,23 +96,50 @@ __global__ __launch_bounds__(kChainThreads) void env_chain_kernel(
       }
       const float v = x0 * a0 + x1 * a1;
       nxt[o * kChainTS + sl] = v;
-      if (cs.env_out_off >= 0)
+      if (LOGMODE) {
+        atomicMax(&sMax[sl], __float_as_uint(fabsf(v)));   // non-negative floats order like their bits
+      } else if (cs.env_out_off >= 0) {
         env_base[cs.env_out_off + (size_t)o * b_pad + s] = v;
-      else
+      } else {
         f[(size_t)o * b_pad + s] = v;
+      }
     }
     __syncthreads();
+    if (LOGMODE) {
+      const float mx = __uint_as_float(sMax[sl]);
+      const float inv = (mx > 0.f && isfinite(mx)) ? 1.0f / mx : 1.0f;
+      for (int o = og; o < cs.n_out; o += OG) nxt[o * kChainTS + sl] *= inv;
+      __syncthreads();
+      if (tid < kChainTS) {
+        const float m2 = __uint_as_float(sMax[tid]);
+        sScale[tid] += (m2 > 0.f && isfinite(m2)) ? logf(m2) : (m2 > 0.f ? INFINITY : -INFINITY);
+        sMax[tid] = 0u;
+      }
+      __syncthreads();
+    }
     float *t = cur; cur = nxt; nxt = t;
+  }
+  if (LOGMODE) {
+    // after the label site the renormalised max |f| of every sample is 1: log max|f| = sScale
+    if (tid < kChainTS) {
+      float v = (blockIdx.x * kChainTS + tid < b) ? sScale[tid] : -INFINITY;
+      for (int off = kChainTS / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+      if (tid == 0) logmax_out[blockIdx.x] = v;
+    }
   }
 }
 
 void launch_env_chain(const ChainSite *sites_dev, int n_sites, const float *cores, const float *labcore,
                       const float *X, float *env_base, float *f, int b, int b_pad, int L, int Mmax,
-                      hipStream_t st) {
+                      float *logmax_out, hipStream_t st) {
   const int mo = Mmax > L ? Mmax : L;
-  size_t lds = ((size_t)Mmax * kD * mo + 2 * (size_t)mo * kChainTS + kChainTS * kD) * sizeof(float);
-  hipLaunchKernelGGL(env_chain_kernel, dim3(b_pad / kChainTS), dim3(kChainThreads), lds, st, sites_dev,
-                     n_sites, cores, labcore, X, env_base, f, b, b_pad, L, Mmax);
+  size_t lds = ((size_t)Mmax * kD * mo + 2 * (size_t)mo * kChainTS + kChainTS * kD + 2 * kChainTS) * sizeof(float);
+  if (logmax_out)
+    hipLaunchKernelGGL(env_chain_kernel<true>, dim3(b_pad / kChainTS), dim3(kChainThreads), lds, st, sites_dev,
+                       n_sites, cores, labcore, X, env_base, f, b, b_pad, L, Mmax, logmax_out);
+  else
+    hipLaunchKernelGGL(env_chain_kernel<false>, dim3(b_pad / kChainTS), dim3(kChainThreads), lds, st, sites_dev,
+                       n_sites, cores, labcore, X, env_base, f, b, b_pad, L, Mmax, logmax_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -114,8 +149,14 @@ void launch_env_chain(const ChainSite *sites_dev, int n_sites, const float *core
 __device__ inline void act_and_lossder(const float *fin, int st_in, float *fa, float *g, int st, int L,
                                        int y, int act_fn, int loss_fn, float T, float &sumabs,
                                        int &correct, int &nonfinite) {
+  // bit 8 of act_fn: the input already went through the activation (compute_loss_derivate's
+  // argument); the low bits still select the cross-entropy formula (Network_class.py:826-830)
+  const bool pre_activated = (act_fn & 0x100) != 0;
+  act_fn &= 0xff;
   // activation
-  if (act_fn == TNML_ACT_SOFTMAX) {
+  if (pre_activated) {
+    for (int l = 0; l < L; ++l) fa[l * st] = fin[l * st_in];
+  } else if (act_fn == TNML_ACT_SOFTMAX) {
     float mx = -INFINITY;
     for (int l = 0; l < L; ++l) mx = fmaxf(mx, fin[l * st_in]);
     float sum = 0.f;

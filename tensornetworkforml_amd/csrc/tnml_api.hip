@@ -368,6 +368,20 @@ extern "C" int tnml_set_input(tnml_ctx *c, const float *X, const int32_t *y, int
   return TNML_OK;
 }
 
+extern "C" int tnml_set_labels(tnml_ctx *c, const int32_t *y, int b) {
+  if (!c || !y) return fail(TNML_ERR_ARG, "NULL argument");
+  if (!c->have_input) return fail(TNML_ERR_STATE, "no input batch: call tnml_set_input first");
+  if (b != c->b) return fail(TNML_ERR_ARG, "labels (%d) and resident batch (%d) differ in length", b, c->b);
+  for (int i = 0; i < b; ++i)
+    if (y[i] < 0 || y[i] >= c->L) return fail(TNML_ERR_ARG, "label %d of sample %d outside [0, %d)", y[i], i, c->L);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemsetAsync(c->y, 0, (size_t)c->b_pad * sizeof(int), c->stream));
+  HIP_TRY(hipMemcpyAsync(c->y, y, (size_t)b * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->have_labels = true;
+  return TNML_OK;
+}
+
 static int copy_f_out(tnml_ctx *c, const float *src_dev, float *f_out) {
   // [L][b_pad] on the device -> [L][b] on the host
   HIP_TRY(hipMemcpy2DAsync(f_out, (size_t)c->b * sizeof(float), src_dev, (size_t)c->b_pad * sizeof(float),
@@ -379,8 +393,7 @@ static int copy_f_out(tnml_ctx *c, const float *src_dev, float *f_out) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-extern "C" int tnml_forward(tnml_ctx *c, float *f_out) {
-  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+static int run_chain(tnml_ctx *c, bool logmode) {
   if (!c->cores_set) return fail(TNML_ERR_STATE, "cores were never set");
   if (!c->have_input) return fail(TNML_ERR_STATE, "no input batch: call tnml_set_input first");
   if (c->l_pos != 0 && c->l_pos != c->N - 1)
@@ -412,7 +425,8 @@ extern "C" int tnml_forward(tnml_ctx *c, float *f_out) {
   HIP_TRY(hipStreamSynchronize(c->stream));   // tab is a stack object
   if (c->profile) HIP_TRY(hipEventRecord(c->pev0, c->stream));
   launch_env_chain((const ChainSite *)c->tables, N, c->cores, c->lab[c->lab_cur], c->X,
-                   right_envs ? c->Renv : c->Lenv, c->f, c->b, c->b_pad, L, c->Mmax, c->stream);
+                   right_envs ? c->Renv : c->Lenv, c->f, c->b, c->b_pad, L, c->Mmax,
+                   logmode ? c->slabs : nullptr, c->stream);
   HIP_TRY(hipGetLastError());
   if (c->profile) {
     HIP_TRY(hipEventRecord(c->pev1, c->stream));
@@ -421,11 +435,40 @@ extern "C" int tnml_forward(tnml_ctx *c, float *f_out) {
     HIP_TRY(hipEventElapsedTime(&ms, c->pev0, c->pev1));
     c->prof_ms[0] += ms; c->prof_n[0]++;
   }
-  c->envs_valid_R = right_envs;
-  c->envs_valid_L = !right_envs;
-  c->f_current = true;
-  c->Bnew_valid = false;
+  if (!logmode) {
+    c->envs_valid_R = right_envs;
+    c->envs_valid_L = !right_envs;
+    c->f_current = true;
+    c->Bnew_valid = false;
+  }
+  return TNML_OK;
+}
+
+extern "C" int tnml_forward(tnml_ctx *c, float *f_out) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  int rc = run_chain(c, false);
+  if (rc) return rc;
   if (f_out) return copy_f_out(c, c->f, f_out);
+  return TNML_OK;
+}
+
+extern "C" int tnml_forward_logabsmax(tnml_ctx *c, double *out) {
+  if (!c || !out) return fail(TNML_ERR_ARG, "NULL argument");
+  int rc = run_chain(c, true);
+  if (rc) return rc;
+  const int nb = c->b_pad / kChainSamplesPerBlock;
+  std::vector<float> part(nb);
+  HIP_TRY(hipMemcpyAsync(part.data(), c->slabs, nb * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  float best = -INFINITY;
+  for (float v : part) best = std::max(best, v);
+  if (c->comm) {
+    HIP_TRY(hipMemcpyAsync(c->scal, &best, sizeof(float), hipMemcpyHostToDevice, c->stream));
+    NCCL_TRY(ncclAllReduce(c->scal, c->scal, 1, ncclFloat, ncclMax, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(&best, c->scal, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  *out = best;
   return TNML_OK;
 }
 
@@ -459,11 +502,15 @@ extern "C" int tnml_get_f(tnml_ctx *c, float *f_out) {
   return copy_f_out(c, c->f, f_out);
 }
 
-extern "C" int tnml_activation(tnml_ctx *c, int act_fn, int loss_fn, float T, float *act_out, float *lossder_out) {
+extern "C" int tnml_activation(tnml_ctx *c, int act_fn, int loss_fn, float T, int input_is_activated, float *act_out,
+                               float *lossder_out) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  if (!c->have_input) return fail(TNML_ERR_STATE, "no resident batch");
+  if (lossder_out && !c->have_labels) return fail(TNML_ERR_STATE, "the loss derivative needs labels");
+  if (act_fn < 0 || act_fn > 2 || loss_fn < 0 || loss_fn > 2) return fail(TNML_ERR_ARG, "unknown activation / loss");
   HIP_TRY(hipSetDevice(c->device));
-  launch_activation(c->f, c->have_labels ? c->y : nullptr, c->L, c->b, c->b_pad, act_fn, loss_fn, T, c->ftmp,
-                    c->ftmp2, c->stream);
+  launch_activation(c->f, c->have_labels ? c->y : nullptr, c->L, c->b, c->b_pad,
+                    act_fn | (input_is_activated ? 0x100 : 0), loss_fn, T, c->ftmp, c->ftmp2, c->stream);
   HIP_TRY(hipGetLastError());
   if (act_out) { int rc = copy_f_out(c, c->ftmp, act_out); if (rc) return rc; }
   if (lossder_out) { int rc = copy_f_out(c, c->ftmp2, lossder_out); if (rc) return rc; }

@@ -91,7 +91,8 @@ struct NormChainSite {
 void launch_transpose_input(const float *X_bnd, float *X_nbd, int b, int b_pad, int N, hipStream_t st);
 void launch_env_chain(const ChainSite *sites_dev, int n_sites, const float *cores, const float *labcore,
                       const float *X, float *env_base, float *f, int b, int b_pad, int L, int Mmax,
-                      hipStream_t st);
+                      float *logmax_out, hipStream_t st);
+constexpr int kChainSamplesPerBlock = 16;
 void launch_wide(const WideParams &p, int nblk, hipStream_t st);
 void launch_f_only(const WideParams &p, int nblk, hipStream_t st);
 void launch_reduce(const float *slabs, int nblk, int slab_stride, int n, float *red, hipStream_t st);

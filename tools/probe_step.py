@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""GPU probe: per-kernel time and Jacobi sweep counts of the sweep step on a headline-shaped chain
+(short N so that it runs in seconds).  Usage: python tools/probe_step.py [N] [M] [b] [L]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tensornetworkforml_amd import _hip                      # noqa: E402
+from tensornetworkforml_amd.Network_class import random_canonical_cores  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+M = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+b = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
+L = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+D = 2
+rng = np.random.default_rng(1)
+p = rng.random((b, N), dtype=np.float32) * (rng.random((b, N), dtype=np.float32) > 0.81)
+X = np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32)
+y = rng.integers(0, L, b).astype(np.int32)
+ctx = _hip.Context(N, D, L, M, b)
+ctx.set_cores(random_canonical_cores(N, M, D, L, scale=M * 0.5 * 0.64 * D, rng=rng), 0)
+ctx.set_input(X, y)
+ctx.scale_cores(1.0 / float(np.exp(ctx.forward_logabsmax() / N)))
+hp = (1e-3, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
+
+
+def one_pass(**kw):
+    ctx.forward(want_f=False)
+    left = ctx.l_pos == N - 1
+    return ctx.sweep(left, N - 1, True, *hp, **kw)
+
+
+one_pass(want_metrics=False, want_f=False)
+one_pass(want_metrics=False, want_f=False)
+# sweep counts, step by step
+ctx.debug_enable(True)
+ctx.forward(want_f=False)
+left = ctx.l_pos == N - 1
+sw = []
+for k in range(N - 1):
+    ctx.sweep(left, 1, k == 0, *hp)
+    sc = ctx.step_debug('scalars')
+    sw.append((int(sc[3]), int(sc[4])))
+ctx.debug_enable(False)
+print('jacobi (sweeps, n) per step:', sw[:6], '...', sw[len(sw) // 2], '...', sw[-3:])
+print('mean sweeps (interior):', np.mean([s for s, n in sw if n == 2 * M]))
+# timing: whole passes, then per kernel
+ctx.synchronize()
+ctx.timer_start()
+for _ in range(4):
+    one_pass(want_metrics=False, want_f=False)
+ms = ctx.timer_stop()
+print('pass: %.3f ms  -> %.1f us per sweep step (incl. forward)' % (ms / 4, 1e3 * ms / 4 / (N - 1)))
+ctx.profile_reset()
+ctx.profile_enable(True)
+one_pass(want_metrics=False, want_f=False)
+ctx.profile_enable(False)
+for i, nm in enumerate(['env_chain', 'wide', 'reduce', 'narrow']):
+    t, n = ctx.profile_get(i)
+    print('%-10s avg %.1f us over %d launches' % (nm, 1e3 * t / max(n, 1), n))
+ctx.close()
