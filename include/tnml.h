@@ -62,7 +62,8 @@ enum {
   TNML_DBG_DB_RAW = 1,   /* bond gradient before weight decay      same shape                    */
   TNML_DBG_B_NEW = 2,    /* updated, un-truncated merged tensor    same shape                    */
   TNML_DBG_SIGMA = 3,    /* all singular values, descending        [min(rows, cols)]             */
-  TNML_DBG_L2 = 4,       /* {L2 loss term, sum|B|, sum|dB|, jacobi sweeps, n rotations}  [5]     */
+  TNML_DBG_L2 = 4,       /* {L2 loss term, sum|B|, sum|dB|, jacobi sweeps, n, cycles before /
+                            in / after the Jacobi loop, 100 MHz ticks of the whole kernel}  [9]  */
   TNML_DBG_L2_GRAD = 5   /* 2*wd*Ln.B.Rn (or wd*B)                 same shape as B               */
 };
 

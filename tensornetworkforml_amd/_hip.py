@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtnml_hip.so')
+LIB_PATH = os.environ.get('TNML_LIB', os.path.join(_HERE, 'libtnml_hip.so'))   # TNML_LIB: experiment builds
 
 ACT = {'linear': 0, 'sigmoid': 1, 'softmax': 2}
 LOSS = {'MSE': 0, 'cross_entropy': 1, 'full_cross_ent': 2}
@@ -247,7 +247,8 @@ class Context:
         return out[:self.b * m.value].reshape(self.b, m.value).copy()
 
     def debug_enable(self, on=True):
-        _chk(lib().tnml_debug_enable(self._h, int(bool(on))))
+        """True / 1: capture every step's tensors; 2: cycle stamps only; False / 0: off."""
+        _chk(lib().tnml_debug_enable(self._h, int(on)))
 
     def step_debug(self, what):
         cap = 4 * max(self.M, self.D * self.L) ** 2 * self.D * self.D * self.L + 64

@@ -77,7 +77,7 @@ __device__ inline void block_sum3(double &a, double &b, double &c, double *scrat
 
 struct NarrowCarve {
   double *dT, *dG, *Z, *dNh, *dNg, *dLam, *dRed, *dT2, *dCS;
-  float *fB, *sLab, *sPl, *sCb;
+  float *fB, *fBp, *sLab, *sPl, *sCb;
   int *sOrd, *sFlag, *sPi, *sPiInv;
   size_t bytes;
 };
@@ -100,6 +100,7 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
   k.dCS = d; d += 4 * ne;                   // (c, s, t, -) per pair, two rounds in flight
   float *f = (float *)d;
   k.fB = f; f += Bs;
+  k.fBp = f; f += Bs + (size_t)(D * h < D * g * L ? D * h : D * g * L) + 4;   // rows at stride (cols + 1): bank-conflict-free
   k.sLab = f; f += (size_t)h * D * s * L;
   k.sPl = f; f += (size_t)s * D * g;
   k.sCb = f; f += (size_t)r * m;
@@ -127,6 +128,10 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   const bool short_rows = (r <= c);
   const int n = short_rows ? r : c, ne = n + (n & 1), len = short_rows ? c : r;
 
+  unsigned long long t_c0 = 0, t_r0 = 0, t_c1 = 0, t_c2 = 0, t_c2b = 0, t_c2c = 0;
+  unsigned long long t_p[5] = {0, 0, 0, 0, 0};
+#define TNML_STAMP(i) if (p.stamps && tid == 0) t_p[i] = __builtin_amdgcn_s_memtime()
+  if (p.stamps && tid == 0) { t_c0 = __builtin_amdgcn_s_memtime(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
   // ---- phase 0: stage the two cores and the norm environments ---------------------------------
   for (int e = tid; e < h * D * s * L; e += NT) {
     const int l = e % L, q = e / L;
@@ -143,37 +148,44 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   for (int e = tid; e < g * g; e += NT) k.dNg[e] = p.Ng ? p.Ng[e] : 1.0;
   __syncthreads();
 
+  TNML_STAMP(0);
   // ---- phase 1: B[h,dk,dk1,g,l] = sum_s lab(h,dk,s,l) * pl(s,dk1,g) ---------------------------
   const int RW = D * D * g * L;  // elements per behind-bond index
   for (int e = tid; e < Bs; e += NT) {
     const int l = e % L, q = e / L;
     const int g_ = q % g, q2 = q / g;
     const int dk1 = q2 % D, q3 = q2 / D;   // q3 = h_*D + dk
-    double acc = 0.0;
-    for (int s_ = 0; s_ < s; ++s_)
-      acc += (double)k.sLab[(q3 * s + s_) * L + l] * (double)k.sPl[(s_ * D + dk1) * g + g_];
-    k.fB[e] = (float)acc;
+    const float *pa = k.sLab + q3 * s * L + l, *pb = k.sPl + dk1 * g + g_;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int s_ = 0; s_ < s; ++s_) acc = fmaf(pa[s_ * L], pb[s_ * D * g], acc);
+    k.fB[e] = acc;
   }
   __syncthreads();
 
+  TNML_STAMP(1);
   // ---- phases 2-3: weight decay term ------------------------------------------------------------
   if (p.l2_flag) {
     for (int e = tid; e < Bs; e += NT) {          // T = Nh^T . B over the behind bond
       const int a_out = e / RW, rest = e % RW;
       double acc = 0.0;
-      for (int a = 0; a < h; ++a) acc += k.dNh[a * h + a_out] * (double)k.fB[a * RW + rest];
+#pragma unroll 4
+      for (int a = 0; a < h; ++a) acc = fma(k.dNh[a * h + a_out], (double)k.fB[a * RW + rest], acc);
       k.dT[e] = acc;
     }
     __syncthreads();
     for (int e = tid; e < Bs; e += NT) {          // G = T . Ng over the ahead bond
       const int l = e % L, q = e / L;
       const int f_ = q % g, pre = q / g;
+      const double *pt = k.dT + pre * g * L + l;
       double acc = 0.0;
-      for (int cc = 0; cc < g; ++cc) acc += k.dT[(pre * g + cc) * L + l] * k.dNg[cc * g + f_];
+#pragma unroll 4
+      for (int cc = 0; cc < g; ++cc) acc = fma(pt[cc * L], k.dNg[cc * g + f_], acc);
       k.dG[e] = acc;
     }
     __syncthreads();
   }
+  TNML_STAMP(2);
   double sumB = 0.0, sumD = 0.0, l2 = 0.0;
   for (int e = tid; e < Bs; e += NT) {
     const double bv = (double)k.fB[e];
@@ -205,6 +217,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   for (int e = tid; e < Bs; e += NT) {
     const float v = (float)((double)k.fB[e] + factor * k.dG[e]);
     k.fB[e] = v;
+    k.fBp[e + e / c] = v;                 // row e / c starts at (e / c) * (c + 1)
     p.Bnew[e] = v;
     if (p.dbg) p.dbg[2 * (size_t)Bs + e] = (double)v;
   }
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   }
   __syncthreads();   // dT/dG are dead from here on; Z aliases them
 
+  TNML_STAMP(3);
   // ---- phase 6: Gram matrix in float64 (padded to ne x ne with a zero row/column), V = I ----------
   //   W(x, kk) = short_rows ? Bm[kk][x] : Bm[x][kk]   with Bm = B_new as (r x c) row-major
   double *G0 = k.Z, *G1 = k.Z + ne * ne, *V0 = k.Z + 2 * ne * ne, *V1 = k.Z + 3 * ne * ne;
@@ -227,10 +241,13 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     double acc = 0.0;
     if (col < n && kk < n && kk <= col) {
       if (short_rows) {
-        const float *ra = k.fB + kk * c, *rb = k.fB + col * c;
-        for (int x = 0; x < len; ++x) acc += (double)ra[x] * (double)rb[x];
+        // consecutive threads walk consecutive rows: the stride c + 1 spreads them over the banks
+        const float *ra = k.fBp + kk * (c + 1), *rb = k.fBp + col * (c + 1);
+#pragma unroll 4
+        for (int x = 0; x < len; ++x) acc = fma((double)ra[x], (double)rb[x], acc);
       } else {
-        for (int x = 0; x < len; ++x) acc += (double)k.fB[x * c + kk] * (double)k.fB[x * c + col];
+#pragma unroll 4
+        for (int x = 0; x < len; ++x) acc = fma((double)k.fB[x * c + kk], (double)k.fB[x * c + col], acc);
       }
     }
     if (kk <= col) { G0[kk * ne + col] = acc; G0[col * ne + kk] = acc; }
@@ -250,6 +267,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     k.sPiInv[nxt] = pos;
   }
   __syncthreads();
+  TNML_STAMP(4);
   // scale G to trace ~ 1 by an exact power of two (undone on the eigenvalues in phase 8)
   double tr = 0.0;
   for (int j = 0; j < n; ++j) tr += G0[j * ne + j];
@@ -269,14 +287,37 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   const int NW = NT - T0;
   int sweeps = 0, converged = 0;
   double *Gc = G0, *Gn = G1, *Vc = V0, *Vn = V1;
-  bool itValid[2];
-  int itP[2], itQ[2];
+  // items: the np(np+1)/2 blocks P <= Q of the symmetric G (only entries with row <= column are kept
+  // up to date), then the np*np blocks of V; at most 2 per worker thread (n <= 64)
+  constexpr int MAXI = 2;
+  const int nG = np * (np + 1) / 2;
+  bool itValid[MAXI], itV[MAXI], itDiag[MAXI];
+  int itSrc[MAXI], itCsQ[MAXI], itCsP[MAXI], itD11[MAXI], itD12[MAXI], itD21[MAXI], itD22[MAXI];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < MAXI; ++u) {
     const int it = (tid - T0) + u * NW;
-    itValid[u] = tid >= T0 && it < np * np;
-    itP[u] = it / np;
-    itQ[u] = it - itP[u] * np;
+    itValid[u] = tid >= T0 && it < nG + np * np;
+    itV[u] = it >= nG;
+    int P = 0, Q = 0;
+    if (itValid[u]) {
+      if (itV[u]) { P = (it - nG) / np; Q = (it - nG) - P * np; }
+      else {                                  // it-th pair (P <= Q) in row-major order of the upper triangle
+        int rem = it;
+        while (rem >= np - P) { rem -= np - P; ++P; }
+        Q = P + rem;
+      }
+    }
+    const int c1 = k.sPi[2 * Q], c2 = k.sPi[2 * Q + 1];
+    const int o1 = itV[u] ? 2 * P : k.sPi[2 * P], o2 = itV[u] ? 2 * P + 1 : k.sPi[2 * P + 1];
+    itSrc[u] = (2 * P) * ne + 2 * Q;
+    itCsQ[u] = 4 * Q; itCsP[u] = 4 * P;
+    itDiag[u] = (!itV[u]) && P == Q;
+    if (itV[u]) {
+      itD11[u] = o1 * ne + c1; itD12[u] = o1 * ne + c2; itD21[u] = o2 * ne + c1; itD22[u] = o2 * ne + c2;
+    } else {                                  // G: every element lands at (min, max) of its new position
+      itD11[u] = min(o1, c1) * ne + max(o1, c1); itD12[u] = min(o1, c2) * ne + max(o1, c2);
+      itD21[u] = min(o2, c1) * ne + max(o2, c1); itD22[u] = min(o2, c2) * ne + max(o2, c2);
+    }
   }
   const double abs2 = kJacobiAbs * kJacobiAbs;      // trace is ~1 after scaling
   // parameter-thread constants
@@ -299,6 +340,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   };
 
   int cur = 0;
+  if (p.stamps && tid == 0) t_c1 = __builtin_amdgcn_s_memtime();
   if (n > 1) {
     double kept2 = kept_scale(Gc);
     if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
@@ -322,44 +364,62 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
           const double bA = Gc[(2 * pA + 1) * ne + 2 * pA + 1];
           const double2 dB = *reinterpret_cast<const double2 *>(Gc + (2 * pB) * ne + 2 * pB);
           const double bB = Gc[(2 * pB + 1) * ne + 2 * pB + 1];
-          const double2 r0 = *reinterpret_cast<const double2 *>(Gc + (2 * pA) * ne + 2 * pB);
-          const double2 r1 = *reinterpret_cast<const double2 *>(Gc + (2 * pA + 1) * ne + 2 * pB);
+          double2 r0, r1;                                       // rows of block (A, B)
+          if (pA < pB) {
+            r0 = *reinterpret_cast<const double2 *>(Gc + (2 * pA) * ne + 2 * pB);
+            r1 = *reinterpret_cast<const double2 *>(Gc + (2 * pA + 1) * ne + 2 * pB);
+          } else if (pA > pB) {                                 // stored as (B, A): transpose
+            const double2 s0 = *reinterpret_cast<const double2 *>(Gc + (2 * pB) * ne + 2 * pA);
+            const double2 s1 = *reinterpret_cast<const double2 *>(Gc + (2 * pB + 1) * ne + 2 * pA);
+            r0 = make_double2(s0.x, s1.x);
+            r1 = make_double2(s0.y, s1.y);
+          } else {                                              // n == 2: the pair meets itself again
+            r0 = dA;
+            r1 = make_double2(dA.y, bA);
+          }
           const double na = ra ? fma(tA, dA.y, bA) : fma(-tA, dA.y, dA.x);
           const double nb = rb ? fma(tB, dB.y, bB) : fma(-tB, dB.y, dB.x);
           // element (ra, rb) of R_A^T . blk . R_B
           const double h0 = ra ? fma(csA.y, r0.x, csA.x * r1.x) : fma(csA.x, r0.x, -csA.y * r1.x);
           const double h1 = ra ? fma(csA.y, r0.y, csA.x * r1.y) : fma(csA.x, r0.y, -csA.y * r1.y);
           const double ng = rb ? fma(csB.y, h0, csB.x * h1) : fma(csB.x, h0, -csB.y * h1);
+#ifdef TNML_EXP_NO_PARAM
+          Rot r; r.c = 0.8; r.s = 0.6; r.t = 0.75; r.level = 2; r.c += 1e-300 * (na + nb + ng);
+#else
           const Rot r = jacobi_rot(na, nb, ng, kept2, abs2);
+#endif
           double *o = k.dCS + ((cur ^ 1) * np + tid) * 4;
           o[0] = r.c; o[1] = r.s; o[2] = r.t;
           if (r.level >= 1) k.sFlag[0] = 1;
           if (r.level >= 2) k.sFlag[1] = 1;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < MAXI; ++u) {
           if (!itValid[u]) continue;
-          const int P = itP[u], Q = itQ[u];
-          const double2 csq = *reinterpret_cast<const double2 *>(csc + 4 * Q);
-          const double2 csp = *reinterpret_cast<const double2 *>(csc + 4 * P);
-          const int c1 = k.sPi[2 * Q], c2 = k.sPi[2 * Q + 1];
-          const int o1 = k.sPi[2 * P], o2 = k.sPi[2 * P + 1];
-          const double2 r0 = *reinterpret_cast<const double2 *>(Gc + (2 * P) * ne + 2 * Q);
-          const double2 r1 = *reinterpret_cast<const double2 *>(Gc + (2 * P + 1) * ne + 2 * Q);
-          const double2 v0 = *reinterpret_cast<const double2 *>(Vc + (2 * P) * ne + 2 * Q);
-          const double2 v1 = *reinterpret_cast<const double2 *>(Vc + (2 * P + 1) * ne + 2 * Q);
-          const double h11 = csp.x * r0.x - csp.y * r1.x, h12 = csp.x * r0.y - csp.y * r1.y;
-          const double h21 = csp.y * r0.x + csp.x * r1.x, h22 = csp.y * r0.y + csp.x * r1.y;
+#ifdef TNML_EXP_NO_V
+          if (itV[u]) continue;
+#endif
+#ifdef TNML_EXP_NO_G
+          if (!itV[u]) continue;
+#endif
+          const double2 csq = *reinterpret_cast<const double2 *>(csc + itCsQ[u]);
+          const double *src = (itV[u] ? Vc : Gc) + itSrc[u];
+          double *dst = itV[u] ? Vn : Gn;
+          const double2 r0 = *reinterpret_cast<const double2 *>(src);
+          double2 r1 = *reinterpret_cast<const double2 *>(src + ne);
+          if (itDiag[u]) r1.x = r0.y;                           // lower element of a diagonal block = its mirror
+          double h11 = r0.x, h12 = r0.y, h21 = r1.x, h22 = r1.y;
+          if (!itV[u]) {                                        // rows by R_P^T (G only; V keeps its rows)
+            const double2 csp = *reinterpret_cast<const double2 *>(csc + itCsP[u]);
+            h11 = csp.x * r0.x - csp.y * r1.x; h12 = csp.x * r0.y - csp.y * r1.y;
+            h21 = csp.y * r0.x + csp.x * r1.x; h22 = csp.y * r0.y + csp.x * r1.y;
+          }
           double n11 = csq.x * h11 - csq.y * h12, n12 = csq.y * h11 + csq.x * h12;
           double n21 = csq.x * h21 - csq.y * h22, n22 = csq.y * h21 + csq.x * h22;
-          if (P == Q && csq.y != 0.0) { n12 = 0.0; n21 = 0.0; }   // the annihilated element, exactly
-          Gn[o1 * ne + c1] = n11; Gn[o1 * ne + c2] = n12;
-          Gn[o2 * ne + c1] = n21; Gn[o2 * ne + c2] = n22;
-          // eigenvectors: columns only, rows stay in place
-          Vn[(2 * P) * ne + c1] = csq.x * v0.x - csq.y * v0.y;
-          Vn[(2 * P) * ne + c2] = csq.y * v0.x + csq.x * v0.y;
-          Vn[(2 * P + 1) * ne + c1] = csq.x * v1.x - csq.y * v1.y;
-          Vn[(2 * P + 1) * ne + c2] = csq.y * v1.x + csq.x * v1.y;
+          if (itDiag[u] && csq.y != 0.0) { n12 = 0.0; n21 = 0.0; }   // the annihilated element, exactly
+          dst[itD11[u]] = n11; dst[itD12[u]] = n12;
+          if (!itDiag[u]) dst[itD21[u]] = n21;                  // (n21 of a diagonal block is n12's mirror)
+          dst[itD22[u]] = n22;
         }
         __syncthreads();
         double *tsw = Gc; Gc = Gn; Gn = tsw;
@@ -370,7 +430,11 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
       // next round: any ne-1 consecutive rounds form a complete sweep
       const int any_rot = k.sFlag[0], big_rot = k.sFlag[1];
       __syncthreads();
+#ifdef TNML_EXP_FIXED_SWEEPS
+      if (sweeps + 1 >= TNML_EXP_FIXED_SWEEPS) { converged = 1; ++sweeps; break; }
+#else
       if (!any_rot || !big_rot) { converged = 1; ++sweeps; break; }
+#endif
       if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
       kept2 = kept_scale(Gc);
     }
@@ -378,6 +442,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     converged = 1;
   }
   double *V = Vc;
+  if (p.stamps && tid == 0) t_c2 = __builtin_amdgcn_s_memtime();
 
   // ---- phase 8: eigenvalues = diag(G), descending order -------------------------------------------
   for (int j = tid; j < n; j += NT) k.dLam[j] = __builtin_amdgcn_ldexp(fmax(Gc[j * ne + j], 0.0), sc_exp);
@@ -385,6 +450,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   for (int j = tid; j < n; j += NT) {
     const double lj = k.dLam[j];
     int rank = 0;
+#pragma unroll 8
     for (int i = 0; i < n; ++i) {
       const double li = k.dLam[i];
       rank += (li > lj) || (li == lj && i < j);
@@ -402,6 +468,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   }
   __syncthreads();
 
+  if (p.stamps && tid == 0) t_c2b = __builtin_amdgcn_s_memtime();
   // ---- phase 9: the two new cores -----------------------------------------------------------------
   const double lam_max = k.dLam[k.sOrd[0]];
   // short-side factor: q_j * sigma_j^(1/2)
@@ -427,10 +494,12 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     const double *q = V + j;                // q[kk] = V[kk][j], stride ne
     double acc = 0.0;
     if (short_rows) {                       // x = column index, sum over rows
-      for (int kk = 0; kk < n; ++kk) acc += (double)k.fB[(size_t)kk * c + x] * q[(size_t)kk * ne];
+#pragma unroll 4
+      for (int kk = 0; kk < n; ++kk) acc = fma((double)k.fB[kk * c + x], q[kk * ne], acc);
     } else {                                // x = row index, sum over columns
-      const float *row = k.fB + (size_t)x * c;
-      for (int kk = 0; kk < n; ++kk) acc += (double)row[kk] * q[(size_t)kk * ne];
+      const float *row = k.fB + x * c;
+#pragma unroll 4
+      for (int kk = 0; kk < n; ++kk) acc = fma((double)row[kk], q[kk * ne], acc);
     }
     const double isq = (lam > 1e-300 && lam > 1e-30 * lam_max) ? 1.0 / sqrt(sqrt(lam)) : 0.0;
     const float v = (float)(acc * isq);
@@ -444,22 +513,36 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   }
   __syncthreads();
 
+  if (p.stamps && tid == 0) t_c2c = __builtin_amdgcn_s_memtime();
   // ---- phase 10: behind norm environment of the next step ------------------------------------------
   if (p.Nh_new) {
     for (int e = tid; e < h * D * m; e += NT) {     // T2[(h_,d), s''] = sum_h' Nh[h_,h'] Cb[(h',d), s'']
       const int sp = e % m, q = e / m;
       const int d = q % D, h_ = q / D;
       double acc = 0.0;
-      for (int hq = 0; hq < h; ++hq) acc += k.dNh[h_ * h + hq] * (double)k.sCb[(hq * D + d) * m + sp];
+#pragma unroll 4
+      for (int hq = 0; hq < h; ++hq) acc = fma(k.dNh[h_ * h + hq], (double)k.sCb[(hq * D + d) * m + sp], acc);
       k.dT2[e] = acc;
     }
     __syncthreads();
     for (int e = tid; e < m * m; e += NT) {
       const int s2 = e % m, s1 = e / m;
       double acc = 0.0;
-      for (int q = 0; q < h * D; ++q) acc += (double)k.sCb[q * m + s1] * k.dT2[q * m + s2];
+#pragma unroll 4
+      for (int q = 0; q < h * D; ++q) acc = fma((double)k.sCb[q * m + s1], k.dT2[q * m + s2], acc);
       p.Nh_new[e] = acc;
     }
+  }
+
+  if (p.stamps && tid == 0) {
+    // diagnostic stamps: shader cycles before / in / after the Jacobi loop and the 100 MHz real-time
+    // counter, from which the host derives the clock the kernel ran at; they go to a buffer nothing
+    // else reads
+    const unsigned long long t_c3 = __builtin_amdgcn_s_memtime(), t_r3 = __builtin_amdgcn_s_memrealtime();
+    p.stamps[0] = (double)(t_c1 - t_c0); p.stamps[1] = (double)(t_c2 - t_c1); p.stamps[2] = (double)(t_c3 - t_c2);
+    p.stamps[3] = (double)(t_r3 - t_r0); p.stamps[4] = (double)sweeps; p.stamps[5] = (double)n;
+    for (int i = 0; i < 5; ++i) p.stamps[9 + i] = (double)(t_p[i] - (i ? t_p[i - 1] : t_c0));
+    p.stamps[6] = (double)(t_c2b - t_c2); p.stamps[7] = (double)(t_c2c - t_c2b); p.stamps[8] = (double)(t_c3 - t_c2c);
   }
 
   // ---- phase 11: metrics of this step (var_hist, Network_class.py:739-750) --------------------------

@@ -421,24 +421,35 @@ void launch_f_only(const WideParams &p, int nblk, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // red[e] = sum over slabs, in slab order (deterministic).  One thread per element.
 // ------------------------------------------------------------------------------------------
-__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int nblk, int slab_stride, int n,
-                                    float *__restrict__ red) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int k = 0;
-  for (; k + 4 <= nblk; k += 4) {
-    a0 += slabs[(size_t)k * slab_stride + e];
-    a1 += slabs[(size_t)(k + 1) * slab_stride + e];
-    a2 += slabs[(size_t)(k + 2) * slab_stride + e];
-    a3 += slabs[(size_t)(k + 3) * slab_stride + e];
+// 64 consecutive elements x 16 slab chunks per workgroup; chunk partials meet in LDS in chunk order.
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float *__restrict__ slabs, int nblk,
+                                                            int slab_stride, int n, float *__restrict__ red) {
+  __shared__ float part[16][64];
+  const int el = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const int per = (nblk + 15) / 16;
+  const int k0 = chunk * per, k1 = min(nblk, k0 + per);
+  float a0 = 0.f, a1 = 0.f;
+  if (e < n) {
+    int k = k0;
+    for (; k + 2 <= k1; k += 2) {
+      a0 += slabs[(size_t)k * slab_stride + e];
+      a1 += slabs[(size_t)(k + 1) * slab_stride + e];
+    }
+    if (k < k1) a0 += slabs[(size_t)k * slab_stride + e];
   }
-  for (; k < nblk; ++k) a0 += slabs[(size_t)k * slab_stride + e];
-  red[e] = (a0 + a1) + (a2 + a3);
+  part[chunk][el] = a0 + a1;
+  __syncthreads();
+  if (chunk == 0 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t += part[c][el];
+    red[e] = t;
+  }
 }
 
 void launch_reduce(const float *slabs, int nblk, int slab_stride, int n, float *red, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 127) / 128), dim3(128), 0, st, slabs, nblk, slab_stride, n,
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, slabs, nblk, slab_stride, n,
                      red);
 }
 

@@ -58,7 +58,7 @@ struct tnml_ctx {
   int prev_h = 0, prev_g = 0; // dims of Bnew (relative frame)
   int prev_left_dir = 0, prev_p = -1;
   int last_bsize = 0, last_n = 0, last_h = 0, last_g = 0, last_left_dir = 0;
-  bool debug = false, profile = false;
+  bool debug = false, profile = false, stamps = false;
   double prof_ms[4] = {0, 0, 0, 0};
   long long prof_n[4] = {0, 0, 0, 0};
   // device buffers
@@ -181,7 +181,7 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   c->metrics_cap = N;
   HIP_TRY(hipMalloc(&c->metrics, (size_t)c->metrics_cap * 2 * sizeof(float)));
   HIP_TRY(hipMalloc(&c->scal, 64 * sizeof(float)));
-  c->dbg_elems = 4 * c->bmax + 64 + 16;
+  c->dbg_elems = 4 * c->bmax + 64 + 24;   // 4 tensors, sigma[64], 5 scalars, 9 stamps
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
   HIP_TRY(hipMalloc(&c->status, sizeof(int)));
   HIP_TRY(hipMemsetAsync(c->status, 0, sizeof(int), c->stream));
@@ -717,6 +717,7 @@ extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_s
     n.out_ahead = c->lab[c->lab_cur ^ 1];
     n.metrics = c->metrics + 2 * (size_t)step;
     n.dbg = c->debug ? c->dbg : nullptr;
+    n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + 64 + 5 : nullptr;
     n.status = c->status;
     prof_begin(c);
     launch_narrow(n, lds, c->stream);
@@ -792,18 +793,20 @@ extern "C" int tnml_get_env(tnml_ctx *c, int side, int site, float *out, size_t 
 
 extern "C" int tnml_debug_enable(tnml_ctx *c, int on) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
-  c->debug = on != 0;
+  c->debug = (on & 1) != 0;    // 1: full capture of every step
+  c->stamps = (on & 2) != 0;   // 2: cycle stamps only (timing runs)
   return TNML_OK;
 }
 
 extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t capacity, size_t *n_out) {
   if (!c || !out) return fail(TNML_ERR_ARG, "NULL argument");
-  if (!c->debug) return fail(TNML_ERR_STATE, "debug capture is off (tnml_debug_enable)");
+  if (!c->debug && !(c->stamps && what == TNML_DBG_L2)) return fail(TNML_ERR_STATE, "debug capture is off (tnml_debug_enable)");
   if (c->last_bsize <= 0) return fail(TNML_ERR_STATE, "no step has run yet");
   HIP_TRY(hipSetDevice(c->device));
   const size_t Bs = c->last_bsize;
-  std::vector<double> hbuf(4 * Bs + 64 + 16);
-  HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, hbuf.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  std::vector<double> hbuf(4 * Bs + 64 + 24);   // tensors, sigma, 5 scalars, 14 stamps
+  HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, (4 * Bs + 64 + 5) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + 64 + 5, c->dbg + 4 * c->bmax + 64 + 5, 14 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   auto tensor_out = [&](size_t block) -> int {
     if (capacity < Bs) return fail(TNML_ERR_ARG, "capacity too small");
@@ -831,9 +834,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
       if (n_out) *n_out = c->last_n;
       return TNML_OK;
     case TNML_DBG_L2:
-      if (capacity < 5) return fail(TNML_ERR_ARG, "capacity too small");
-      memcpy(out, hbuf.data() + 4 * Bs + 64, 5 * sizeof(double));
-      if (n_out) *n_out = 5;
+      if (capacity < 19) return fail(TNML_ERR_ARG, "capacity too small");
+      memcpy(out, hbuf.data() + 4 * Bs + 64, 19 * sizeof(double));
+      if (n_out) *n_out = 19;
       return TNML_OK;
   }
   return fail(TNML_ERR_ARG, "unknown debug selector %d", what);

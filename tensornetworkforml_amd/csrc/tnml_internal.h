@@ -12,7 +12,7 @@ namespace tnml {
 
 constexpr int kD = 2;           // feature dimension the kernels are specialised for
 constexpr int kTS = 32;         // samples per workgroup in the wide step kernel (v1)
-constexpr int kWideThreads = 256;
+constexpr int kWideThreads = 1024; // 4 waves per SIMD: the v1 formulation is latency-bound
 constexpr int kNarrowThreads = 1024;
 constexpr int kMetricSlots = 4; // per-slab tail: correct count, sum|y-fa|, non-finite count, pad
 
@@ -79,6 +79,7 @@ struct NarrowParams {
   double *Nh_new;          // out: behind norm env of the next step (m x m)
   float *metrics;          // out: (accuracy, MAE) of this step
   double *dbg;             // debug block (see narrow kernel), may be nullptr
+  double *stamps;          // 4 doubles of cycle stamps (diagnostic), may be nullptr
   int *status;             // device status word: bit0 non-finite, bit1 jacobi not converged
 };
 

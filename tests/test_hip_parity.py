@@ -95,7 +95,8 @@ def test_stepwise_vs_oracle_and_golden(name):
     ctx.debug_enable(True)
     y1h = mo.one_hot(y, L)
     k = 0
-    worst = {}
+    worst = {'B': 0.0, 'dB_raw': 0.0, 'L2_grad': 0.0, 'B_new': 0.0}
+    degenerate_seen = False
 
     def upd(key, v):
         worst[key] = max(worst.get(key, 0.0), v)
@@ -116,12 +117,19 @@ def test_stepwise_vs_oracle_and_golden(name):
             met, f_d = ctx.sweep(left_dir, 1, j == 0, kw['lr'], kw['weight_dec'], kw['L2_flag'], kw['act_fn'],
                                  kw['loss_fn'], kw['T'], kw['trunc'])
             shp = rec['B'].shape
-            B_d = canon_to(ctx.step_debug('B'), shp)
-            sa, tc = gauge_signs(B_d, rec['B'])
-            upd('B', relerr(B_d, regauge(rec['B'], sa, tc)))
-            upd('dB_raw', relerr(canon_to(ctx.step_debug('dB_raw'), shp), regauge(rec['dB_raw'], sa, tc)))
-            upd('L2_grad', relerr(canon_to(ctx.step_debug('L2_grad'), shp), regauge(rec['L2_grad'], sa, tc)))
-            upd('B_new', relerr(canon_to(ctx.step_debug('B_new'), shp), regauge(rec['B_new'], sa, tc)))
+            if not degenerate_seen:
+                B_d = canon_to(ctx.step_debug('B'), shp)
+                sa, tc = gauge_signs(B_d, rec['B'])
+                upd('B', relerr(B_d, regauge(rec['B'], sa, tc)))
+                upd('dB_raw', relerr(canon_to(ctx.step_debug('dB_raw'), shp), regauge(rec['dB_raw'], sa, tc)))
+                upd('L2_grad', relerr(canon_to(ctx.step_debug('L2_grad'), shp), regauge(rec['L2_grad'], sa, tc)))
+                upd('B_new', relerr(canon_to(ctx.step_debug('B_new'), shp), regauge(rec['B_new'], sa, tc)))
+            # Once two kept singular values (nearly) coincide, the singular vectors -- hence every
+            # later merged tensor -- are defined only up to a rotation inside that subspace: the
+            # tensors stop being comparable element-wise, sigma / f / metrics still are.
+            Sk = rec['S'][:rec['m'] + 1]
+            if len(Sk) > 1 and np.min(-np.diff(Sk)) < 2e-3 * rec['S'][0]:
+                degenerate_seen = True
             sig = ctx.step_debug('sigma')
             upd('sigma', np.abs(sig - rec['S']).max() / rec['S'].max())
             upd('f_new', relerr(f_d, f_o))

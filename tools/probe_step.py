@@ -26,6 +26,17 @@ ctx.scale_cores(1.0 / float(np.exp(ctx.forward_logabsmax() / N)))
 hp = (1e-3, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
 
 
+def stamp_line(tag, sc):
+    cyc = sc[5] + sc[6] + sc[7]
+    print('%s: cycles pre/jacobi/post = %d / %d / %d ; kernel %.1f us ; clock %.2f GHz ; sweeps %d n %d ; %.0f cycles per round'
+          % (tag, sc[5], sc[6], sc[7], sc[8] / 100.0, cyc / max(sc[8] / 100.0, 1e-9) / 1e3, sc[9], sc[10],
+             sc[6] / max(1, sc[9] * (sc[10] - 1))))
+    if len(sc) > 18:
+        print('   pre split: load %d / B %d / L2 %d / sums+update %d / gram %d cycles' % tuple(sc[14:19]))
+    if len(sc) > 13:
+        print('   post split: sort %d / cores %d / norm env + metrics %d cycles' % (sc[11], sc[12], sc[13]))
+
+
 def one_pass(**kw):
     ctx.forward(want_f=False)
     left = ctx.l_pos == N - 1
@@ -43,16 +54,31 @@ for k in range(N - 1):
     ctx.sweep(left, 1, k == 0, *hp)
     sc = ctx.step_debug('scalars')
     sw.append((int(sc[3]), int(sc[4])))
+    if k == (N - 1) // 2:
+        stamp_line('isolated mid step', sc)
 ctx.debug_enable(False)
 print('jacobi (sweeps, n) per step:', sw[:6], '...', sw[len(sw) // 2], '...', sw[-3:])
 print('mean sweeps (interior):', np.mean([s for s, n in sw if n == 2 * M]))
 # timing: whole passes, then per kernel
 ctx.synchronize()
+import time
+t0 = time.perf_counter()
 ctx.timer_start()
 for _ in range(4):
     one_pass(want_metrics=False, want_f=False)
+t_enq = time.perf_counter() - t0
 ms = ctx.timer_stop()
+print('host enqueue: %.1f us per sweep step (GPU pass time below)' % (1e6 * t_enq / 4 / (N - 1)))
 print('pass: %.3f ms  -> %.1f us per sweep step (incl. forward)' % (ms / 4, 1e3 * ms / 4 / (N - 1)))
+# stamps of the last step of a full-speed sweep (stops half way so that the last step is an interior one)
+ctx.debug_enable(2)
+ctx.forward(want_f=False)
+left = ctx.l_pos == N - 1
+ctx.sweep(left, N // 2, True, *hp, want_metrics=False, want_f=False)
+ctx.synchronize()
+stamp_line('back-to-back mid step', ctx.step_debug('scalars'))
+ctx.sweep(left, N - 1 - N // 2, False, *hp, want_metrics=False, want_f=False)
+ctx.debug_enable(0)
 ctx.profile_reset()
 ctx.profile_enable(True)
 one_pass(want_metrics=False, want_f=False)
