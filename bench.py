@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--no-l2', action='store_true', help='weight decay as wd*B instead of the L2 norm term')
     ap.add_argument('--cpu-steps', type=int, default=40, help='oracle steps timed for cpu_baseline (0 = skip)')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--no-cold', action='store_true', help='skip the re-initialised (cold start) passes')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -101,30 +102,26 @@ def main():
     N, M, b, L = CONFIGS[args.config]
     D = 2
 
+    from tensornetworkforml_amd import _hip, dist as tdist
     dist = None
     if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-
-    from tensornetworkforml_amd import _hip
+        dist = tdist.init_process_group(rank, world, 'gloo')     # rendezvous only; the data path is RCCL
     if _hip.device_count() <= local_rank:
         raise SystemExit('bench.py needs a gfx950 GPU per rank (visible: %d)' % _hip.device_count())
     ctx = _hip.Context(N, D, L, M, b, device=local_rank)
-    if world > 1:
-        import torch
-        uid = [_hip.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(rank, world, uid[0])
+    tdist.attach_comm(ctx, rank, world)
 
     X, y = synth(N, b, L, 1234 + rank)          # every rank owns a different shard
     cores = init_cores(N, M, D, L, 99)            # same cores on every rank
-    ctx.set_cores(cores, 0)
     ctx.set_input(X, y)
-    # calibration on the same batch (Network_class.py:168-176)
-    F2 = float(np.exp(ctx.forward_logabsmax() / N))   # log-domain: max|f| ~ 1e-66 before calibration
-    ctx.scale_cores(1.0 / F2)
+
+    def init_network():
+        ctx.set_cores(cores, 0)
+        # calibration on the same batch (Network_class.py:168-176); log-domain: max|f| ~ 1e-66 before it
+        F2 = float(np.exp(ctx.forward_logabsmax() / N))
+        ctx.scale_cores(1.0 / F2)
+
+    init_network()
 
     hp = dict(lr=1e-3, weight_dec=1e-3, L2_flag=not args.no_l2, act_fn='softmax', loss_fn='full_cross_ent', T=0.1,
               trunc=args.policy)
@@ -144,6 +141,7 @@ def main():
     for _ in range(args.warmup):
         one_pass()
     barrier()
+    ctx.svd_stats(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_pass()
@@ -155,6 +153,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    sw_tot, n_svd, rounds_tot = ctx.svd_stats(reset=True)
     # validity: one more pass handing back metrics and f; non-finite values raise inside the library
     met, f = one_pass(want=True)
     finite = bool(np.isfinite(f).all() and np.isfinite(met).all())
@@ -180,6 +179,8 @@ def main():
                    'global_batch': b * world, 'sweep_steps_per_pass': N - 1, 'parallelism': 'dp%d' % world},
         'finite': finite,
         'final_accuracy': float(met[-1, 0]),
+        # the SVD is iterative: how much work the timed passes actually contained
+        'jacobi': {'sweeps_per_svd': sw_tot / max(n_svd, 1), 'rounds_per_svd': rounds_tot / max(n_svd, 1)},
     }
 
     if rank == 0 and not args.no_kernel_profile:
@@ -206,6 +207,27 @@ def main():
         # keep the collectives of the profiling passes matched on every rank
         one_pass()
         one_pass()
+
+    if not args.no_cold:
+        # "cold" passes: network re-initialised (random cores, calibrated) and swept twice -- the regime
+        # of the first training batches, where the merged tensors are far from their SVD form and the
+        # Jacobi iteration needs its full 7-9 sweeps
+        init_network()
+        barrier()
+        ctx.svd_stats(reset=True)
+        t0 = time.perf_counter()
+        one_pass()
+        one_pass()
+        barrier()
+        dtc = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([dtc], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtc = float(t.item())
+        sw_c, n_c, _ = ctx.svd_stats(reset=True)
+        out['cold_start'] = {'value': 2 * (N - 1) / dtc, 'unit': 'sweep-steps/s', 'passes': 2,
+                             'jacobi_sweeps_per_svd': sw_c / max(n_c, 1)}
 
     if rank == 0 and args.cpu_steps > 0:
         rate, t_fwd, t_step = cpu_baseline(N, M, D, L, b, args.cpu_steps, 1234)

@@ -150,6 +150,9 @@ int tnml_timer_stop(tnml_ctx *ctx, double *elapsed_ms);
 int tnml_profile_enable(tnml_ctx *ctx, int on);
 int tnml_profile_get(tnml_ctx *ctx, int which, double *ms, long long *launches);
 int tnml_profile_reset(tnml_ctx *ctx);
+/* always-on counters of the Jacobi SVD since the last reset:
+ *   out3 = {total sweeps, number of SVDs, total rounds (one barrier each)} */
+int tnml_svd_stats(tnml_ctx *ctx, int reset, double *out3);
 
 /* Host-side planning helper, exported so that CPU tests can check the bond bookkeeping without a
  * GPU: truncation rank kept by tensor_svd (Network_class.py:894-945) for a step on sites

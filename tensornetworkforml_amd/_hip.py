@@ -25,7 +25,7 @@ SYMBOLS = [
     'tnml_get_cores', 'tnml_scale_cores', 'tnml_set_input', 'tnml_set_labels', 'tnml_forward', 'tnml_forward_logabsmax', 'tnml_f_absmax',
     'tnml_set_f', 'tnml_get_f', 'tnml_sweep', 'tnml_activation', 'tnml_get_env', 'tnml_debug_enable',
     'tnml_get_step_debug', 'tnml_l_pos', 'tnml_batch', 'tnml_timer_start', 'tnml_timer_stop',
-    'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_trunc_rank',
+    'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
 ]
 
 
@@ -80,6 +80,7 @@ def lib():
         L.tnml_profile_enable.argtypes = [vp, C.c_int]
         L.tnml_profile_get.argtypes = [vp, C.c_int, f64p, C.POINTER(C.c_longlong)]
         L.tnml_profile_reset.argtypes = [vp]
+        L.tnml_svd_stats.argtypes = [vp, C.c_int, f64p]
         L.tnml_trunc_rank.argtypes = [C.c_int] * 9
         _lib = L
     return _lib
@@ -278,6 +279,12 @@ class Context:
 
     def profile_reset(self):
         _chk(lib().tnml_profile_reset(self._h))
+
+    def svd_stats(self, reset=False):
+        """(total Jacobi sweeps, SVDs, total rounds) since the last reset."""
+        out = (C.c_double * 3)()
+        _chk(lib().tnml_svd_stats(self._h, int(bool(reset)), out))
+        return out[0], out[1], out[2]
 
     def profile_get(self, which):
         ms, n = C.c_double(), C.c_longlong()

@@ -459,6 +459,11 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     if (p.dbg) p.dbg[4 * (size_t)Bs + rank] = sqrt(lj);
   }
   if (tid == 0) {
+    if (p.counters) {
+      atomicAdd(p.counters, (unsigned long long)sweeps);
+      atomicAdd(p.counters + 1, 1ull);
+      atomicAdd(p.counters + 2, (unsigned long long)sweeps * (unsigned long long)(ne - 1));
+    }
     if (!converged) atomicOr(p.status, 2);
     if (p.dbg) {
       double *sc = p.dbg + 4 * (size_t)Bs + 64;

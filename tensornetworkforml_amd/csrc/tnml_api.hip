@@ -75,6 +75,7 @@ struct tnml_ctx {
   double *dbg = nullptr;
   size_t dbg_elems = 0;
   int *status = nullptr;
+  unsigned long long *counters = nullptr;
   void *tables = nullptr;      // device scratch for ChainSite / NormChainSite tables
   size_t tables_bytes = 0;
   // multi-GPU
@@ -185,6 +186,8 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
   HIP_TRY(hipMalloc(&c->status, sizeof(int)));
   HIP_TRY(hipMemsetAsync(c->status, 0, sizeof(int), c->stream));
+  HIP_TRY(hipMalloc(&c->counters, 4 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(c->counters, 0, 4 * sizeof(unsigned long long), c->stream));
   c->tables_bytes = (size_t)N * std::max(sizeof(ChainSite), sizeof(NormChainSite));
   HIP_TRY(hipMalloc(&c->tables, c->tables_bytes));
   int rc = alloc_batch_buffers(c, b_capacity);
@@ -200,7 +203,7 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
   void *ptrs[] = {c->X, c->Xstage, c->y, c->f, c->ftmp, c->ftmp2, c->Lenv, c->Renv, c->cores, c->lab[0], c->lab[1],
-                  c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables};
+                  c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -719,6 +722,7 @@ extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_s
     n.dbg = c->debug ? c->dbg : nullptr;
     n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + 64 + 5 : nullptr;
     n.status = c->status;
+    n.counters = c->counters;
     prof_begin(c);
     launch_narrow(n, lds, c->stream);
     prof_end(c, 3);
@@ -872,6 +876,17 @@ extern "C" int tnml_profile_get(tnml_ctx *c, int which, double *ms, long long *l
   if (launches) *launches = c->prof_n[which];
   return TNML_OK;
 }
+extern "C" int tnml_svd_stats(tnml_ctx *c, int reset, double *out3) {
+  if (!c || !out3) return fail(TNML_ERR_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  unsigned long long h[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  out3[0] = (double)h[0]; out3[1] = (double)h[1]; out3[2] = (double)h[2];
+  if (reset) HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof h, c->stream));
+  return TNML_OK;
+}
+
 extern "C" int tnml_profile_reset(tnml_ctx *c) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   for (int i = 0; i < 4; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }

@@ -79,7 +79,8 @@ struct NarrowParams {
   double *Nh_new;          // out: behind norm env of the next step (m x m)
   float *metrics;          // out: (accuracy, MAE) of this step
   double *dbg;             // debug block (see narrow kernel), may be nullptr
-  double *stamps;          // 4 doubles of cycle stamps (diagnostic), may be nullptr
+  double *stamps;          // cycle stamps (diagnostic), may be nullptr
+  unsigned long long *counters;  // [0] += jacobi sweeps, [1] += SVDs, [2] += jacobi rounds (always on)
   int *status;             // device status word: bit0 non-finite, bit1 jacobi not converged
 };
 

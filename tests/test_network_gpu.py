@@ -1,0 +1,200 @@
+"""GPU tests through the reference-style Python API (`Network_class.Network`), as a driver written
+against the reference would use it."""
+import contextlib
+import io
+import pickle
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import tensornetworkforml_amd as pkg
+from tensornetworkforml_amd import _hip
+from Network_class import Network, _core_to_tensor
+from Tensor_class import Tensor
+import data_generator as gen
+from oracle import mps_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def net_from_golden(d, **kw):
+    N, M, L, D = int(d['N']), int(d['M']), int(d['L']), int(d['D'])
+    with quiet():
+        net = Network(N=N, M=M, D=D, L=L, T=float(d['T']), act_fn=str(d['act_fn']), loss_fn=str(d['loss_fn']),
+                      trunc=str(d['policy']), **kw)
+    net.As = [_core_to_tensor(c, i, N, i == 0) for i, c in enumerate(gu.indexed(d, 'init_core', N))]
+    return net
+
+
+@pytest.mark.parametrize('name', ['traj_reference_N16_script', 'traj_fixed_N16_script', 'traj_fixed_L3',
+                                  'traj_reference_softmax_full_cross_ent_L21', 'traj_fixed_sigmoid_MSE_L20'])
+def test_train_loop_matches_reference(name):
+    """forward / accuracy / sweep exactly as Network.train drives them, against the reference's
+    per-step accuracy, MAE and f."""
+    d = gu.load(name)
+    N = int(d['N'])
+    net = net_from_golden(d)
+    X, y = d['X'], d['y']
+    k = 0
+    for sw in range(int(d['n_sweeps'])):
+        f = net.forward(X)
+        assert relerr(f.elem, d['sw%d_f_forward' % sw]) < 2e-3
+        assert list(f.axes_names) == ['l', 'b']
+        left_dir = (net.l_pos == N - 1)
+        assert left_dir == bool(d['sw%d_left_dir' % sw])
+        vh = [[], []]
+        f = net.sweep(X, y, f, float(d['lr']), float(d['wd']), L2_flag=bool(d['L2_flag']), left_dir=left_dir, var_hist=vh)
+        ref_acc = [float(d['st%d_accuracy' % (k + j)]) for j in range(N - 1)]
+        ref_mae = [float(d['st%d_MAE' % (k + j)]) for j in range(N - 1)]
+        assert np.abs(np.array(vh[0]) - ref_acc).max() < 1e-6
+        assert np.abs(np.array(vh[1]) - ref_mae).max() < 2e-3
+        k += N - 1
+        assert relerr(f.elem, d['st%d_f_new' % (k - 1)]) < 5e-3
+        assert net.l_pos == (0 if left_dir else N - 1)
+    assert relerr(net.forward(X).elem, d['final_f']) < 5e-3
+    assert abs(net.accuracy(X, y) - mo.accuracy(d['final_f'], y)) < 1e-9
+
+
+def test_sweep_step_api_and_env_lists():
+    d = gu.load('traj_fixed_softmax_full_cross_ent_L21')
+    N, L = int(d['N']), int(d['L'])
+    net = net_from_golden(d)
+    X, y = d['X'], d['y']
+    f = net.forward(X)
+    # r_cum_contraction as the reference leaves it after forward at l_pos = 0 (Network_class.py:240-242)
+    r = net.r_cum_contraction
+    assert len(r) == N and net.l_cum_contraction is None
+    assert list(r[0].axes_names) == ['l', 'b'] and relerr(r[0].elem, d['sw0_f_forward']) < 2e-5
+    for i in (1, N // 2, N - 1):
+        assert list(r[i].axes_names) == ['left', 'b']
+        assert relerr(r[i].elem.T, d['sw0_fw_Renv%d' % i]) < 2e-5
+    assert len(net.TX) == N and list(net.TX[3].axes_names) == ['b', 'd3']
+    one_hot = np.zeros((y.size, L)); one_hot[np.arange(y.size), y] = 1
+    for k in range(N - 1):
+        vh = [[], []]
+        f = net.sweep_step(f, one_hot.T, float(d['lr']), len(y), float(d['wd']), L2_flag=True, left_dir=False, var_hist=vh)
+        assert relerr(f.elem, d['st%d_f_new' % k]) < 5e-3
+        assert abs(vh[0][0] - float(d['st%d_accuracy' % k])) < 1e-6
+        assert net.l_pos == k + 1
+        assert len(net.l_cum_contraction) == max(0, k)        # grown one entry per step from the second on
+    with pytest.raises(Exception):
+        net.sweep_step(f, one_hot.T, 0.1, len(y), 0.1)         # l_pos == N-1: not allowed for a right step
+    lc = net.l_cum_contraction
+    assert list(lc[0].axes_names) == ['right', 'b'] and lc[0].elem.shape[1] == len(y)
+    # forward at an intermediate position raises, as the reference does (Network_class.py:258)
+    f = net.forward(X)
+    net.sweep_step(f, one_hot.T, 0.1, len(y), 0.1, left_dir=True)
+    with pytest.raises(Exception):
+        net.forward(X)
+    with pytest.raises(AssertionError):
+        net.forward(X[:, :-1])
+
+
+def test_As_names_mutation_and_pickle():
+    d = gu.load('traj_fixed_N16_script')
+    N, M, L = int(d['N']), int(d['M']), int(d['L'])
+    net = net_from_golden(d)
+    X, y = d['X'], d['y']
+    f0 = net.forward(X).elem
+    As = net.As
+    assert len(As) == N
+    assert sorted(As[0].axes_names) == sorted(['d0', 'right', 'l']) and sorted(As[3].axes_names) == sorted(['left', 'd3', 'right'])
+    assert sorted(As[N - 1].axes_names) == sorted(['left', 'd%d' % (N - 1)])
+    # in-place edit of a handed-out Tensor is picked up by the next device call (Network.__init__'s
+    # calibration loop edits As[i].elem this way, Network_class.py:175-176)
+    net.As[5].elem = net.As[5].elem * 2.0
+    assert relerr(net.forward(X).elem, 2.0 * f0) < 1e-5
+    net.As[5].elem = net.As[5].elem / 2.0
+    # a sweep moves the label: the handed-out list is rebuilt with the new shapes
+    f = net.forward(X)
+    net.sweep(X, y, f, 1e-3, 1e-3)
+    As = net.As
+    assert 'l' in As[N - 1].axes_names and 'l' not in As[0].axes_names
+    # pickle round trip (training_diagonals.py:69-70, test_diagonals.py:41-42)
+    blob = pickle.dumps(net)
+    net2 = pickle.loads(blob)
+    assert net2.l_pos == net.l_pos and net2.trunc == net.trunc
+    assert relerr(net2.forward(X).elem, net.forward(X).elem) < 1e-6
+
+
+def test_shipped_model_state_loads():
+    """The reference's trained_diag_model.dat pickles a plain __dict__ whose As are Tensors in the
+    reference's own axis orders; __setstate__ takes exactly that."""
+    d = gu.load('shipped_diag_model')
+    N, L = int(d['N']), int(d['L'])
+    lp = int(d['l_pos'])
+    As = []
+    for i, c in enumerate(gu.indexed(d, 'core', N)):
+        T = _core_to_tensor(c, i, N, i == lp)
+        T.transpose(list(T.axes_names)[::-1])                    # some other axis order, as in the pickle
+        As.append(T)
+    state = dict(N=N, D=int(d['D']), L=L, M=int(d['M']), T=float(d['T']), As=As, l_pos=lp, act_fn=str(d['act_fn']),
+                 loss_fn=str(d['loss_fn']), TX=None, r_cum_contraction=None, l_cum_contraction=None)
+    net = Network.__new__(Network)
+    net.__setstate__(state)
+    f = net.forward(d['X'])
+    assert relerr(f.elem, d['f']) < 2e-4
+    assert net.accuracy(d['X'], d['y'], f) == 1.0
+    act = net.apply_act_func(f)
+    assert np.abs(act.elem - d['act']).max() < 1e-4
+
+
+@pytest.mark.parametrize('act_fn,loss_fn', [('softmax', 'full_cross_ent'), ('sigmoid', 'MSE'), ('linear', 'cross_entropy'),
+                                            ('softmax', 'cross_entropy')])
+def test_activation_and_loss_derivative(act_fn, loss_fn):
+    rng = np.random.default_rng(1)
+    L, b = 3, 37
+    with quiet():
+        net = Network(N=4, M=2, L=L, act_fn=act_fn, loss_fn=loss_fn)
+    f = Tensor(elem=rng.normal(size=(L, b)) * 0.3 + 0.5, axes_names=['l', 'b'])
+    y = rng.integers(0, L, b)
+    fa = net.apply_act_func(f)
+    ref = mo.apply_act_func(f.elem, act_fn, 0.1)
+    assert np.abs(fa.elem - ref).max() < 2e-6
+    with quiet():
+        g = net.compute_loss_derivate(fa, mo.one_hot(y, L))
+    gref = mo.compute_loss_derivate(ref, mo.one_hot(y, L), act_fn, loss_fn, 0.1)
+    assert relerr(g.elem, gref) < 2e-3
+
+
+def test_calibration_and_diagonals_training_learns():
+    """training_diagonals.py in miniature: the one task the reference learns (val acc -> 1.0)."""
+    np.random.seed(0)
+    data, label = gen.create_dataset(800, 8, 0.7)
+    tr, va, te = gen.prepare_dataset(data, label, 1, 0.2, int(800 * 0.8), 64, 64)
+    xcal = next(iter(tr)).X
+    with quiet():
+        net = Network(N=64, M=4, L=2, calibration_X=xcal, normalize=True, act_fn='softmax', loss_fn='full_cross_ent')
+    fcal = net.forward(xcal)
+    assert abs(np.abs(fcal.elem).max() - 1.0) < 1e-3               # calibrated: max |f| == 1
+    with quiet():
+        val_acc, var_hist = net.train(tr, va, lr=0.01, n_epochs=3, weight_dec=1)
+    assert var_hist.shape == (3, 2, 63)
+    assert val_acc[-1] >= 0.95, val_acc
+    # all interior bonds collapsed to 2 under the reference truncation policy
+    shapes = [A.elem.shape for A in net.As[2:-2]]
+    assert all(sorted(s) == [2, 2, 2] for s in shapes if len(s) == 3)
+
+
+def test_debug_var_hist_has_seven_series():
+    d = gu.load('traj_fixed_softmax_full_cross_ent_L21')
+    net = net_from_golden(d)
+    X, y = d['X'], d['y']
+    f = net.forward(X)
+    vh = [[] for _ in range(7)]
+    net.sweep(X, y, f, float(d['lr']), float(d['wd']), var_hist=vh, debug=True)
+    assert all(len(v) == int(d['N']) - 1 for v in vh)
+    ref_acc = [float(d['st%d_accuracy' % j]) for j in range(int(d['N']) - 1)]
+    assert np.abs(np.array(vh[2]) - ref_acc).max() < 1e-6
+    assert abs(vh[5][0] - float(d['st0_L2_loss'])) <= 1e-3 * abs(float(d['st0_L2_loss'])) + 1e-9
