@@ -199,8 +199,16 @@ def main():
         bstep = bytes_per_step(b, M, D, L)
         wide_us = kern['wide_step_kernel']['avg_us']
         ach = bstep / (wide_us * 1e-6) / 1e9
+        # HBM traffic of that kernel from committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
+        # runs of this command; gfx950 correction: FETCH_SIZE counts half of a coalesced read stream)
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_%s.json' % args.config)
+        if os.path.exists(pmc):
+            w = json.load(open(pmc)).get('wide_step_kernel', {})
+            if 'FETCH_SIZE' in w and 'WRITE_SIZE' in w:
+                traffic = (2.0 * w['FETCH_SIZE']['mean_KB'] + w['WRITE_SIZE']['mean_KB']) * 1024.0
         out['roofline'] = {'bound': 'hbm', 'kernel': 'wide_step_kernel', 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                           'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                           'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                            'algorithmic_bytes_per_launch': bstep,
                            'whole_step_GBs': bstep * value / 1e9}
     elif dist is not None and not args.no_kernel_profile:

@@ -75,6 +75,62 @@ __device__ inline void block_sum3(double &a, double &b, double &c, double *scrat
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------
+// C[M x N] = A[M x K] . B[K x N] on the matrix cores, float64 (v_mfma_f64_16x16x4_f64), for operands
+// that live in LDS.  The 16x16 output tiles are dealt round-robin to the waves of the workgroup;
+// loadA(i, k) / loadB(k, j) / store(i, j, value) are inlined index maps, called with in-range
+// indices only (out-of-range rows, columns and k are fed as zeros).
+// Lane maps (cdna_hip_programming.md section 3): A[row = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][col = lane & 15], C/D col = lane & 15, row = (lane >> 4) + 4 * reg.
+// ------------------------------------------------------------------------------------------
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+
+template <class FA, class FB, class FS>
+__device__ inline void small_gemm_f64(int nbatch, int M, int N, int K, FA loadA, FB loadB, FS store) {
+  // C_b[M x N] = A_b[M x K] . B_b[K x N] for b < nbatch; loadA(b, i, k), loadB(b, k, j),
+  // store(b, i, j, value) must be LINEAR index maps (no run-time divisions: they are evaluated per
+  // element); a composite row index such as (site index, label) is expressed through the batch.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int tn = (N + 15) >> 4, tm = (M + 15) >> 4, per = tm * tn, ntiles = nbatch * per;
+  const int r = lane & 15, q = lane >> 4;
+  for (int t = wave; t < ntiles; t += nw) {
+    const int bt = t / per, tt = t - bt * per;
+    const int ti = tt / tn;
+    const int i0 = ti << 4, j0 = (tt - ti * tn) << 4;
+    const bool va = i0 + r < M, vb = j0 + r < N;
+    const int ia = va ? i0 + r : M - 1, jb = vb ? j0 + r : N - 1;
+    // four k-steps of operands are fetched before the first MFMA of the group, two accumulators
+    // break the MFMA -> MFMA dependency
+    dvec4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k0 + 4 * u + q;
+        const bool vk = kk < K;
+        const int kc = vk ? kk : K - 1;
+        a[u] = loadA(bt, ia, kc);
+        b[u] = loadB(bt, kc, jb);
+        a[u] = (va && vk) ? a[u] : 0.0;
+        b[u] = (vb && vk) ? b[u] : 0.0;
+      }
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
+      if (k0 + 8 < K) {                                    // wave-uniform
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
+      }
+    }
+    const dvec4 acc = acc0 + acc1;
+    const int j = j0 + r;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = i0 + q + 4 * reg;
+      if (i < M && j < N) store(bt, i, j, acc[reg]);
+    }
+  }
+}
+
 struct NarrowCarve {
   double *dT, *dG, *Z, *dNh, *dNg, *dLam, *dRed, *dT2, *dCS;
   float *fB, *fBp, *sLab, *sPl, *sCb;
@@ -151,38 +207,29 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   TNML_STAMP(0);
   // ---- phase 1: B[h,dk,dk1,g,l] = sum_s lab(h,dk,s,l) * pl(s,dk1,g) ---------------------------
   const int RW = D * D * g * L;  // elements per behind-bond index
-  for (int e = tid; e < Bs; e += NT) {
-    const int l = e % L, q = e / L;
-    const int g_ = q % g, q2 = q / g;
-    const int dk1 = q2 % D, q3 = q2 / D;   // q3 = h_*D + dk
-    const float *pa = k.sLab + q3 * s * L + l, *pb = k.sPl + dk1 * g + g_;
-    float acc = 0.f;
-#pragma unroll 4
-    for (int s_ = 0; s_ < s; ++s_) acc = fmaf(pa[s_ * L], pb[s_ * D * g], acc);
-    k.fB[e] = acc;
+  {   // rows i = (h_, dk, l), columns j = (dk1, g_), inner index the shared bond
+    const int QW = D * g;
+    small_gemm_f64(L, h * D, QW, s,
+                   [&](int l, int i, int kk) { return (double)k.sLab[(i * s + kk) * L + l]; },
+                   [&](int l, int kk, int j) { return (double)k.sPl[kk * QW + j]; },
+                   [&](int l, int i, int j, double v) { k.fB[(i * QW + j) * L + l] = (float)v; });
   }
   __syncthreads();
 
   TNML_STAMP(1);
   // ---- phases 2-3: weight decay term ------------------------------------------------------------
   if (p.l2_flag) {
-    for (int e = tid; e < Bs; e += NT) {          // T = Nh^T . B over the behind bond
-      const int a_out = e / RW, rest = e % RW;
-      double acc = 0.0;
-#pragma unroll 4
-      for (int a = 0; a < h; ++a) acc = fma(k.dNh[a * h + a_out], (double)k.fB[a * RW + rest], acc);
-      k.dT[e] = acc;
-    }
+    // T = Nh^T . B over the behind bond:  T[e_, rest] = sum_a Nh[a, e_] B[a, rest]
+    small_gemm_f64(1, h, RW, h,
+                   [&](int, int i, int kk) { return k.dNh[kk * h + i]; },
+                   [&](int, int kk, int j) { return (double)k.fB[kk * RW + j]; },
+                   [&](int, int i, int j, double v) { k.dT[i * RW + j] = v; });
     __syncthreads();
-    for (int e = tid; e < Bs; e += NT) {          // G = T . Ng over the ahead bond
-      const int l = e % L, q = e / L;
-      const int f_ = q % g, pre = q / g;
-      const double *pt = k.dT + pre * g * L + l;
-      double acc = 0.0;
-#pragma unroll 4
-      for (int cc = 0; cc < g; ++cc) acc = fma(pt[cc * L], k.dNg[cc * g + f_], acc);
-      k.dG[e] = acc;
-    }
+    // G = T . Ng over the ahead bond: rows i = (e_, dk, dk1, l), columns f_
+    small_gemm_f64(L, Bs / (g * L), g, g,
+                   [&](int l, int i, int kk) { return k.dT[(i * g + kk) * L + l]; },
+                   [&](int l, int kk, int j) { return k.dNg[kk * g + j]; },
+                   [&](int l, int i, int j, double v) { k.dG[(i * g + j) * L + l] = v; });
     __syncthreads();
   }
   TNML_STAMP(2);
@@ -236,22 +283,27 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   // ---- phase 6: Gram matrix in float64 (padded to ne x ne with a zero row/column), V = I ----------
   //   W(x, kk) = short_rows ? Bm[kk][x] : Bm[x][kk]   with Bm = B_new as (r x c) row-major
   double *G0 = k.Z, *G1 = k.Z + ne * ne, *V0 = k.Z + 2 * ne * ne, *V1 = k.Z + 3 * ne * ne;
-  for (int e = tid; e < ne * ne; e += NT) {
-    const int col = e / ne, kk = e % ne;
-    double acc = 0.0;
-    if (col < n && kk < n && kk <= col) {
-      if (short_rows) {
-        // consecutive threads walk consecutive rows: the stride c + 1 spreads them over the banks
-        const float *ra = k.fBp + kk * (c + 1), *rb = k.fBp + col * (c + 1);
-#pragma unroll 4
-        for (int x = 0; x < len; ++x) acc = fma((double)ra[x], (double)rb[x], acc);
-      } else {
-#pragma unroll 4
-        for (int x = 0; x < len; ++x) acc = fma((double)k.fB[x * c + kk], (double)k.fB[x * c + col], acc);
-      }
-    }
-    if (kk <= col) { G0[kk * ne + col] = acc; G0[col * ne + kk] = acc; }
-    V0[e] = (kk == col) ? 1.0 : 0.0;
+  for (int e = tid; e < ne * ne; e += NT) {           // zero fill (covers the padding) and V = I
+    G0[e] = 0.0;
+    V0[e] = (e / ne == e % ne) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // rows of the padded copy (stride c + 1) keep the 16 lanes of an operand on 16 different banks
+  if (short_rows)
+    small_gemm_f64(1, n, n, len,
+                   [&](int, int i, int x) { return (double)k.fBp[i * (c + 1) + x]; },
+                   [&](int, int x, int j) { return (double)k.fBp[j * (c + 1) + x]; },
+                   [&](int, int i, int j, double v) { G0[i * ne + j] = v; });
+  else
+    small_gemm_f64(1, n, n, len,
+                   [&](int, int i, int x) { return (double)k.fB[x * c + i]; },
+                   [&](int, int x, int j) { return (double)k.fB[x * c + j]; },
+                   [&](int, int i, int j, double v) { G0[i * ne + j] = v; });
+  __syncthreads();
+  // exact symmetry (the two triangles come from different accumulation orders)
+  for (int e = tid; e < n * n; e += NT) {
+    const int i = e / n, j = e % n;
+    if (i < j) G0[j * ne + i] = G0[i * ne + j];
   }
   // Tournament in POSITION space: the pairs of a round are always the positions (2k, 2k+1); after
   // the rotations every row/column moves to position pi(pos) of the next round (circle method:
@@ -341,6 +393,9 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 
   int cur = 0;
   if (p.stamps && tid == 0) t_c1 = __builtin_amdgcn_s_memtime();
+  // the parameter wave's dependent chain is the critical path of every round: let it win the
+  // arbitration for issue slots and LDS against the worker waves of its SIMD
+  if (__builtin_amdgcn_readfirstlane(tid) < T0) __builtin_amdgcn_s_setprio(3);
   if (n > 1) {
     double kept2 = kept_scale(Gc);
     if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
@@ -356,6 +411,9 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     for (; sweeps < kJacobiMaxSweeps; ++sweeps) {
       for (int rnd = 0; rnd < ne - 1; ++rnd) {
         const double *csc = k.dCS + cur * np * 4;
+        const bool stampRound = p.stamps && tid == 0 && sweeps == 0 && rnd == 7;
+        unsigned long long r_t0 = 0, r_t1 = 0, r_t2 = 0, r_t3 = 0;
+        if (stampRound) r_t0 = __builtin_amdgcn_s_memtime();
         if (isParam) {
           const double2 csA = *reinterpret_cast<const double2 *>(csc + 4 * pA);
           const double2 csB = *reinterpret_cast<const double2 *>(csc + 4 * pB);
@@ -386,7 +444,9 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 #ifdef TNML_EXP_NO_PARAM
           Rot r; r.c = 0.8; r.s = 0.6; r.t = 0.75; r.level = 2; r.c += 1e-300 * (na + nb + ng);
 #else
+          if (stampRound) { asm volatile("" :: "v"(na), "v"(nb), "v"(ng)); r_t1 = __builtin_amdgcn_s_memtime(); }
           const Rot r = jacobi_rot(na, nb, ng, kept2, abs2);
+          if (stampRound) { asm volatile("" :: "v"(r.c), "v"(r.s)); r_t2 = __builtin_amdgcn_s_memtime(); }
 #endif
           double *o = k.dCS + ((cur ^ 1) * np + tid) * 4;
           o[0] = r.c; o[1] = r.s; o[2] = r.t;
@@ -422,6 +482,10 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
           dst[itD22[u]] = n22;
         }
         __syncthreads();
+        if (stampRound) {
+          r_t3 = __builtin_amdgcn_s_memtime();
+          p.stamps[14] = (double)(r_t1 - r_t0); p.stamps[15] = (double)(r_t2 - r_t1); p.stamps[16] = (double)(r_t3 - r_t2);
+        }
         double *tsw = Gc; Gc = Gn; Gn = tsw;
         tsw = Vc; Vc = Vn; Vn = tsw;
         cur ^= 1;
@@ -442,6 +506,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     converged = 1;
   }
   double *V = Vc;
+  if (__builtin_amdgcn_readfirstlane(tid) < T0) __builtin_amdgcn_s_setprio(0);
   if (p.stamps && tid == 0) t_c2 = __builtin_amdgcn_s_memtime();
 
   // ---- phase 8: eigenvalues = diag(G), descending order -------------------------------------------
@@ -491,52 +556,48 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
       p.out_ahead[sp * p.oa_s_m + (q / g) * p.oa_s_d + (q % g) * p.oa_s_g + l] = v;
     }
   }
-  // long-side factor: (W q_j) / sigma_j^(1/2)
-  for (int e = tid; e < len * m; e += NT) {
-    const int sp = e % m, x = e / m;
-    const int j = k.sOrd[sp];
-    const double lam = k.dLam[j];
-    const double *q = V + j;                // q[kk] = V[kk][j], stride ne
-    double acc = 0.0;
-    if (short_rows) {                       // x = column index, sum over rows
-#pragma unroll 4
-      for (int kk = 0; kk < n; ++kk) acc = fma((double)k.fB[kk * c + x], q[kk * ne], acc);
-    } else {                                // x = row index, sum over columns
-      const float *row = k.fB + x * c;
-#pragma unroll 4
-      for (int kk = 0; kk < n; ++kk) acc = fma((double)row[kk], q[kk * ne], acc);
-    }
-    const double isq = (lam > 1e-300 && lam > 1e-30 * lam_max) ? 1.0 / sqrt(sqrt(lam)) : 0.0;
-    const float v = (float)(acc * isq);
-    if (short_rows) {
-      const int l = x % L, qq = x / L;
-      p.out_ahead[sp * p.oa_s_m + (qq / g) * p.oa_s_d + (qq % g) * p.oa_s_g + l] = v;
-    } else {
-      k.sCb[x * m + sp] = v;
-      p.out_behind[(x / D) * p.ob_s_h + (x % D) * p.ob_s_d + sp * p.ob_s_m] = v;
-    }
+  // long-side factor: (W q_j) / sigma_j^(1/2); columns s', inner index the short one
+  if (short_rows) {
+    // long index = ahead group x = (dk1, g_, l) = qq * L + l: the label is the batch, rows are qq = (dk1, g_)
+    small_gemm_f64(L, D * g, m, n,
+                   [&](int l, int qq, int kk) { return (double)k.fB[kk * c + qq * L + l]; },
+                   [&](int l, int kk, int sp) { return V[kk * ne + k.sOrd[sp]]; },
+                   [&](int l, int qq, int sp, double acc) {
+                     const double lam = k.dLam[k.sOrd[sp]];
+                     const double isq = (lam > 1e-300 && lam > 1e-30 * lam_max) ? 1.0 / sqrt(sqrt(lam)) : 0.0;
+                     const int dk1 = qq >= g ? 1 : 0;                     // D == 2
+                     p.out_ahead[sp * p.oa_s_m + dk1 * p.oa_s_d + (qq - dk1 * g) * p.oa_s_g + l] = (float)(acc * isq);
+                   });
+  } else {
+    // long index = behind group x = (h_, dk) = h_ * D + dk: dk is the batch, rows are h_
+    small_gemm_f64(D, h, m, n,
+                   [&](int dk, int h_, int kk) { return (double)k.fBp[(h_ * D + dk) * (c + 1) + kk]; },
+                   [&](int dk, int kk, int sp) { return V[kk * ne + k.sOrd[sp]]; },
+                   [&](int dk, int h_, int sp, double acc) {
+                     const double lam = k.dLam[k.sOrd[sp]];
+                     const double isq = (lam > 1e-300 && lam > 1e-30 * lam_max) ? 1.0 / sqrt(sqrt(lam)) : 0.0;
+                     const float v = (float)(acc * isq);
+                     k.sCb[(h_ * D + dk) * m + sp] = v;
+                     p.out_behind[h_ * p.ob_s_h + dk * p.ob_s_d + sp * p.ob_s_m] = v;
+                   });
   }
   __syncthreads();
 
   if (p.stamps && tid == 0) t_c2c = __builtin_amdgcn_s_memtime();
   // ---- phase 10: behind norm environment of the next step ------------------------------------------
   if (p.Nh_new) {
-    for (int e = tid; e < h * D * m; e += NT) {     // T2[(h_,d), s''] = sum_h' Nh[h_,h'] Cb[(h',d), s'']
-      const int sp = e % m, q = e / m;
-      const int d = q % D, h_ = q / D;
-      double acc = 0.0;
-#pragma unroll 4
-      for (int hq = 0; hq < h; ++hq) acc = fma(k.dNh[h_ * h + hq], (double)k.sCb[(hq * D + d) * m + sp], acc);
-      k.dT2[e] = acc;
-    }
+    // T2[h_, (d, s'')] = sum_h' Nh[h_, h'] Cb[h', (d, s'')]
+    const int DM = D * m;
+    small_gemm_f64(1, h, DM, h,
+                   [&](int, int i, int kk) { return k.dNh[i * h + kk]; },
+                   [&](int, int kk, int j) { return (double)k.sCb[kk * DM + j]; },
+                   [&](int, int i, int j, double v) { k.dT2[i * DM + j] = v; });
     __syncthreads();
-    for (int e = tid; e < m * m; e += NT) {
-      const int s2 = e % m, s1 = e / m;
-      double acc = 0.0;
-#pragma unroll 4
-      for (int q = 0; q < h * D; ++q) acc = fma((double)k.sCb[q * m + s1], k.dT2[q * m + s2], acc);
-      p.Nh_new[e] = acc;
-    }
+    // Nh_new[s', s''] = sum_{(h_, d)} Cb[(h_, d), s'] T2[(h_, d), s'']
+    small_gemm_f64(1, m, m, h * D,
+                   [&](int, int i, int kk) { return (double)k.sCb[kk * m + i]; },
+                   [&](int, int kk, int j) { return k.dT2[kk * m + j]; },
+                   [&](int, int i, int j, double v) { p.Nh_new[i * m + j] = v; });
   }
 
   if (p.stamps && tid == 0) {

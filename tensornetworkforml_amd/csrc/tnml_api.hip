@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "tnml_internal.h"
 
@@ -726,6 +727,10 @@ extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_s
     prof_begin(c);
     launch_narrow(n, lds, c->stream);
     prof_end(c, 3);
+    {   // diagnostic: TNML_EXTRA_LAUNCHES=k adds k trivial dependent launches per step (prices a boundary)
+      static const int extra = getenv("TNML_EXTRA_LAUNCHES") ? atoi(getenv("TNML_EXTRA_LAUNCHES")) : 0;
+      for (int x = 0; x < extra; ++x) launch_scale(c->scal, 1, 1.0f, c->stream);
+    }
     // ---- bookkeeping ---------------------------------------------------------------------------
     c->bond[p] = m;
     c->l_pos = sa;
@@ -810,7 +815,7 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
   const size_t Bs = c->last_bsize;
   std::vector<double> hbuf(4 * Bs + 64 + 24);   // tensors, sigma, 5 scalars, 14 stamps
   HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, (4 * Bs + 64 + 5) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + 64 + 5, c->dbg + 4 * c->bmax + 64 + 5, 14 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + 64 + 5, c->dbg + 4 * c->bmax + 64 + 5, 17 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   auto tensor_out = [&](size_t block) -> int {
     if (capacity < Bs) return fail(TNML_ERR_ARG, "capacity too small");
@@ -838,9 +843,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
       if (n_out) *n_out = c->last_n;
       return TNML_OK;
     case TNML_DBG_L2:
-      if (capacity < 19) return fail(TNML_ERR_ARG, "capacity too small");
-      memcpy(out, hbuf.data() + 4 * Bs + 64, 19 * sizeof(double));
-      if (n_out) *n_out = 19;
+      if (capacity < 22) return fail(TNML_ERR_ARG, "capacity too small");
+      memcpy(out, hbuf.data() + 4 * Bs + 64, 22 * sizeof(double));
+      if (n_out) *n_out = 22;
       return TNML_OK;
   }
   return fail(TNML_ERR_ARG, "unknown debug selector %d", what);

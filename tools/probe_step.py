@@ -33,6 +33,8 @@ def stamp_line(tag, sc):
              sc[6] / max(1, sc[9] * (sc[10] - 1))))
     if len(sc) > 18:
         print('   pre split: load %d / B %d / L2 %d / sums+update %d / gram %d cycles' % tuple(sc[14:19]))
+    if len(sc) > 21:
+        print('   one round, parameter wave: loads+new elements %d / rotation %d / stores+barrier %d cycles' % tuple(sc[19:22]))
     if len(sc) > 13:
         print('   post split: sort %d / cores %d / norm env + metrics %d cycles' % (sc[11], sc[12], sc[13]))
 
