@@ -7,6 +7,8 @@
 //
 // Layouts: features x[site][b_pad][D]; environments env[slot][m][b_pad] (bond-major, the batch is
 // the contiguous axis, so a wave reads 64 consecutive samples of one bond index); f [L][b_pad].
+#include <cstdlib>
+
 #include "tnml_internal.h"
 
 namespace tnml {
@@ -405,7 +407,298 @@ __global__ __launch_bounds__(kWideThreads) void f_only_kernel(WideParams p, int 
     p.f[(size_t)(e / kTS) * p.b_pad + s0 + (e % kTS)] = w.sF[e];
 }
 
+// ------------------------------------------------------------------------------------------
+// Wide step kernel, MFMA formulation (v_mfma_f32_16x16x4_f32: exact float32 FMA chains).
+// One workgroup = kTS samples, 8 waves.  All three GEMM-shaped parts put the SAMPLE on the MFMA
+// column (= lane & 15), so per-sample operands are read at consecutive LDS addresses:
+//   (f)   T_l[i, s]  = sum_j B'_l[i, j] Q'[j, s]          i = (h', d), j = (d', g')     waves 0-3
+//         f[l, s]    = sum_i P'[i, s] T_l[i, s]                                         (epilogue)
+//   (env) H[hn, s]   = sum_i A[i, hn] P'[i, s]            P'[i, s] = H'[h', s] x_{k-1}[s, d]   waves 4-7
+//   (dB)  dB_l[i, j] = sum_s (g[l, s] P[i, s]) Q[j, s]    P = H x_k, Q = x_{k+1} G      all waves
+// Operand products are formed once into zero-padded LDS arrays (row counts padded to 16, inner
+// dimensions to 4), so the MFMA loops are two ds_read_b32 + one MFMA per k-step with no guards.
+// Lane maps: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
+// C/D col = lane & 15, row = 4 (lane >> 4) + reg.
+// ------------------------------------------------------------------------------------------
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+constexpr int kMfmaThreads = 512;
+constexpr int kTSP = kTS + 1;           // sample stride of the LDS operand arrays (bank spread)
+
+__host__ __device__ inline int up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct WideMfmaDims {
+  int IP, RS, JP, KA, HS, I3, J3;      // padded sizes (see carve)
+};
+__host__ __device__ inline WideMfmaDims wide_mfma_dims(int hp, int gp, int h, int g) {
+  WideMfmaDims d;
+  d.IP = up(hp * kD, 16);               // rows i = (h', d) of B'_l and of P'
+  d.JP = up(kD * gp, 4);                // inner index j = (d', g') of the f product
+  d.RS = 0;                             // row stride of B' in LDS, set by the caller (needs L)
+  d.KA = up(hp * kD, 4);                // inner index of the env product
+  d.HS = up(h, 16) + 1;                 // row stride of the extension core A[i][hn]
+  d.I3 = up(h * kD, 16);                // rows of dB
+  d.J3 = up(kD * g, 16);                // columns of dB
+  return d;
+}
+struct WideMfmaSmem { float *sX, *sF, *sGl, *sPp, *sQp, *sBp, *sA, *sH, *sPg, *sQ, *rH, *rGp, *rG, *rB, *rA; size_t floats; };
+__host__ __device__ inline WideMfmaSmem wide_mfma_carve(float *base, WideMfmaDims &d, int L, int h, int hp = 0, int gp = 0,
+                                                        int g = 0) {
+  WideMfmaSmem w;
+  d.RS = (d.JP * L) | 1;                // rows of B'[i][(j, l)] at an odd stride: 16 rows -> 16 banks
+  float *q = base;
+  w.sX = q; q += 3 * kTS * kD;
+  w.sF = q; q += L * kTS;
+  w.sGl = q; q += L * kTS;
+  w.sPp = q; q += d.IP * kTSP;                       // P'[i][s]   (also the B operand of the env product)
+  w.sQp = q; q += d.JP * kTSP;                       // Q'[j][s]
+  w.sBp = q; q += (size_t)d.IP * d.RS;               // B'[i][(j, l)] as stored, zero padded
+  w.sA = q; q += d.KA * d.HS;                        // extension core A[i][hn]
+  w.sH = q; q += up(h, 16) * kTSP;                   // H[hn][s]
+  w.sPg = q; q += (size_t)L * d.I3 * kTSP;           // g[l][s] P[i][s]
+  w.sQ = q; q += d.J3 * kTSP;                        // Q[j][s]
+  // raw landing zones of the asynchronous global -> LDS loads (64 floats per wave-instruction)
+  w.rH = q; q += up(hp, 2) * kTS;                    // H' rows   [h'][s]
+  w.rGp = q; q += up(gp, 2) * kTS;                   // G' rows   [g'][s]
+  w.rG = q; q += up(g, 2) * kTS;                     // G rows    [g][s]
+  w.rB = q; q += up(hp * kD * kD * gp * L, 64);      // B' as stored
+  w.rA = q; q += up(hp * kD * h, 64);                // extension core A[i][hn], unpadded
+  w.floats = (size_t)(q - base);
+  return w;
+}
+
+__global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_kernel(WideParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  WideMfmaDims dm = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
+  const WideMfmaSmem w = wide_mfma_carve(smem, dm, p.L, p.h, p.hp, p.gp, p.g);
+  const int tid = threadIdx.x, NT = kMfmaThreads;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int s0 = blockIdx.x * kTS;
+  const int L = p.L, h = p.h, g = p.g, hp = p.hp, gp = p.gp;
+  const int nI = hp * kD, nJ = kD * gp;               // live rows / inner size of the f product
+  constexpr int ST = kTS / 16;                        // sample tiles
+  const bool stamp = p.stamps && blockIdx.x == 0 && tid == 0;
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define WSTAMP(i) if (stamp) ts[i] = __builtin_amdgcn_s_memtime()
+  WSTAMP(0);
+
+  // ---- stage 1: every global read of the workgroup as an asynchronous global -> LDS load
+  // (global_load_lds_dword: 64 consecutive floats of LDS per wave-instruction, per-lane global
+  // address), all in flight together; ONE wait; then the padded operand arrays are built LDS -> LDS.
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+#define GLDS(gp_, lp_) __builtin_amdgcn_global_load_lds((gptr_t)(gp_), (lptr_t)(lp_), 4, 0, 0)
+  const int NWV = NT / 64;
+  const int half = lane >> 5, col = lane & 31;
+  const bool haveH = p.Hprev && !p.first_ext && (p.do_f || p.do_ext);
+  {
+    // x of the three sites: 3 * kTS * kD = 192 floats = 3 wave-instructions
+    if (wave < 3) {
+      const float *src = wave == 0 ? p.x_km1 : (wave == 1 ? p.x_k : p.x_kp1);
+      if (src) GLDS(src + (size_t)s0 * kD + lane, w.sX + wave * 64);
+    }
+    if (haveH)
+      for (int pr = wave; pr < up(hp, 2) / 2; pr += NWV)
+        GLDS(p.Hprev + (size_t)min(2 * pr + half, hp - 1) * p.b_pad + s0 + col, w.rH + pr * 64);
+    if (p.do_f && p.Gprev)
+      for (int pr = wave; pr < up(gp, 2) / 2; pr += NWV)
+        GLDS(p.Gprev + (size_t)min(2 * pr + half, gp - 1) * p.b_pad + s0 + col, w.rGp + pr * 64);
+    if (p.Gcur)
+      for (int pr = wave; pr < up(g, 2) / 2; pr += NWV)
+        GLDS(p.Gcur + (size_t)min(2 * pr + half, g - 1) * p.b_pad + s0 + col, w.rG + pr * 64);
+    if (p.do_f) {
+      const int nB = nI * nJ * L;
+      for (int c = wave; c < up(nB, 64) / 64; c += NWV) GLDS(p.Bprev + min(c * 64 + lane, nB - 1), w.rB + c * 64);
+    }
+    if (p.do_ext) {
+      const int nA = nI * h;
+      for (int c = wave; c < up(nA, 64) / 64; c += NWV) {
+        const int idx = min(c * 64 + lane, nA - 1);
+        const int i = idx / h, o = idx - i * h;
+        GLDS(p.ext_core.base + (i >> 1) * p.ext_core.s_in + (i & 1) * p.ext_core.s_d + o * p.ext_core.s_out, w.rA + c * 64);
+      }
+    }
+    if (!p.do_f)
+      for (int e = tid; e < L * kTS; e += NT) w.sF[e] = p.f[(size_t)(e / kTS) * p.b_pad + s0 + (e % kTS)];
+    if (!p.do_ext)
+      for (int e = tid; e < up(h, 16) * kTS; e += NT) {
+        const int sl = e % kTS, hn = e / kTS;
+        w.sH[hn * kTSP + sl] = hn < h ? (p.Hcur ? p.Hcur[(size_t)hn * p.b_pad + s0 + sl] : 1.0f) : 0.f;
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  WSTAMP(1);
+  __syncthreads();
+
+  // ---- stage 2: padded operand arrays, LDS -> LDS ---------------------------------------------------
+  const float *sXm = w.sX, *sXk = w.sX + kTS * kD, *sXp = w.sX + 2 * kTS * kD;
+  if (p.do_f || p.do_ext)
+    for (int e = tid; e < dm.IP * kTS; e += NT) {       // P'[i][s] = H'[h'][s] x_{k-1}[s][d]
+      const int sl = e % kTS, i = e / kTS;
+      float v = 0.f;
+      if (i < nI) v = (haveH ? w.rH[(i >> 1) * kTS + sl] : 1.0f) * sXm[sl * kD + (i & 1)];
+      w.sPp[i * kTSP + sl] = v;
+    }
+  if (p.do_f) {
+    for (int e = tid; e < dm.JP * kTS; e += NT) {       // Q'[j][s] = x_k[s][d'] G'[g'][s],  j = d' * gp + g'
+      const int sl = e % kTS, j = e / kTS;
+      float v = 0.f;
+      if (j < nJ) {
+        const int dd = j >= gp ? 1 : 0;                 // D == 2
+        v = sXk[sl * kD + dd] * (p.Gprev ? w.rGp[(j - dd * gp) * kTS + sl] : 1.0f);
+      }
+      w.sQp[j * kTSP + sl] = v;
+    }
+    const int rowlen = nJ * L;
+    for (int i = wave; i < dm.IP; i += NWV)             // B'[i][(j, l)] at the odd row stride RS
+      for (int x = lane; x < dm.RS; x += 64)
+        w.sBp[i * dm.RS + x] = (i < nI && x < rowlen) ? w.rB[i * rowlen + x] : 0.f;
+  }
+  if (p.do_ext)
+    for (int i = wave; i < dm.KA; i += NWV)
+      for (int o = lane; o < dm.HS; o += 64)
+        w.sA[i * dm.HS + o] = (i < nI && o < h) ? w.rA[i * h + o] : 0.f;
+  for (int e = tid; e < dm.J3 * kTS; e += NT) {         // Q[j][s] = x_{k+1}[s][dk1] G[g][s],  j = dk1 * g + g_
+    const int sl = e % kTS, j = e / kTS;
+    float v = 0.f;
+    if (j < kD * g) {
+      const int dd = j >= g ? 1 : 0;                    // D == 2
+      v = sXp[sl * kD + dd] * (p.Gcur ? w.rG[(j - dd * g) * kTS + sl] : 1.0f);
+    }
+    w.sQ[j * kTSP + sl] = v;
+  }
+  __syncthreads();
+
+  WSTAMP(2);
+  // ---- f of the previous step (waves 0-3)  ||  extension of the behind environment (waves 4-7) ----
+  if (wave < 4) {
+    if (p.do_f) {
+      for (int cidx = wave; cidx < L * ST; cidx += 4) {
+        const int l = cidx / ST, st = cidx % ST;
+        const float *bq = w.sQp + q * kTSP + st * 16 + r;
+        float facc = 0.f;
+        for (int it = 0; it < dm.IP / 16; ++it) {
+          const float *ap = w.sBp + (it * 16 + r) * dm.RS + q * L + l;      // B'[i][(j, l)], j = 4 kk + q
+          fvec4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 5
+          for (int kk = 0; kk < dm.JP / 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * L], bq[kk * 4 * kTSP], acc, 0, 0, 0);
+          const float *pp = w.sPp + (it * 16 + 4 * q) * kTSP + st * 16 + r;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) facc = fmaf(acc[reg], pp[reg * kTSP], facc);
+        }
+        facc += __shfl_xor(facc, 16);
+        facc += __shfl_xor(facc, 32);
+        if (q == 0) {
+          w.sF[l * kTS + st * 16 + r] = facc;
+          p.f[(size_t)l * p.b_pad + s0 + st * 16 + r] = facc;
+        }
+      }
+    }
+  } else if (p.do_ext) {
+    const int HT = up(h, 16) / 16;
+    for (int cidx = wave - 4; cidx < HT * ST; cidx += 4) {
+      const int ht = cidx / ST, st = cidx % ST;
+      const float *ap = w.sA + q * dm.HS + ht * 16 + r;
+      const float *bq = w.sPp + q * kTSP + st * 16 + r;
+      fvec4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 5
+      for (int kk = 0; kk < dm.KA / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * dm.HS], bq[kk * 4 * kTSP], acc, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int hn = ht * 16 + 4 * q + reg;
+        w.sH[hn * kTSP + st * 16 + r] = acc[reg];                 // rows >= h of the padded tile are zero
+        if (hn < h) p.Hcur[(size_t)hn * p.b_pad + s0 + st * 16 + r] = acc[reg];
+      }
+    }
+  }
+  __syncthreads();
+
+  WSTAMP(3);
+  // ---- activation, metrics, loss derivative (one thread per sample) ------------------------------
+  {
+    // per-sample work on the first kTS threads; the per-sample metric terms go to LDS and one thread
+    // adds them in sample order (deterministic)
+    __shared__ float sMet[3][kTS];
+    if (tid < kTS) {
+      const int s = s0 + tid;
+      float m_abs = 0.f;
+      int m_cor = 0, m_nf = 0;
+      if (s < p.b) {
+        act_and_lossder(w.sF + tid, kTS, w.sGl + tid, w.sGl + tid, kTS, L, p.y[s], p.act_fn, p.loss_fn, p.T, m_abs,
+                        m_cor, m_nf);
+      } else {
+        for (int l = 0; l < L; ++l) w.sGl[l * kTS + tid] = 0.f;    // padded samples carry no gradient
+      }
+      sMet[0][tid] = (float)m_cor; sMet[1][tid] = m_abs; sMet[2][tid] = (float)m_nf;
+    }
+    if (stamp) ts[7] = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if (tid < 3) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < kTS; ++i) t += sMet[tid][i];
+      p.slabs[(size_t)blockIdx.x * p.slab_stride + p.bsize + tid] = t;
+    } else if (tid == 3) {
+      const int valid = p.b - s0;
+      p.slabs[(size_t)blockIdx.x * p.slab_stride + p.bsize + 3] = (float)(valid < 0 ? 0 : (valid > kTS ? kTS : valid));
+    }
+  }
+  WSTAMP(4);
+  // ---- (g P)[l][i][s] ---------------------------------------------------------------------------------
+  for (int l = 0; l < L; ++l)
+    for (int e = tid; e < dm.I3 * kTS; e += NT) {
+      const int sl = e % kTS, i = e / kTS;
+      float v = 0.f;
+      if (i < h * kD) v = w.sGl[l * kTS + sl] * w.sH[(i >> 1) * kTSP + sl] * sXk[sl * kD + (i & 1)];
+      w.sPg[((size_t)l * dm.I3 + i) * kTSP + sl] = v;
+    }
+  __syncthreads();
+
+  WSTAMP(5);
+  // ---- partial bond gradient: one 16x16 tile of dB_l per wave-iteration, K = the kTS samples ---------
+  {
+    const int IT = dm.I3 / 16, JT = dm.J3 / 16, QW = kD * g;
+    float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride;
+    for (int cidx = wave; cidx < L * IT * JT; cidx += NT / 64) {
+      const int jt = cidx % JT, t = cidx / JT;
+      const int it = t % IT, l = t / IT;
+      const float *ap = w.sPg + ((size_t)l * dm.I3 + it * 16 + r) * kTSP + q;
+      const float *bq = w.sQ + (jt * 16 + r) * kTSP + q;
+      fvec4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < kTS / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4], bq[kk * 4], acc, 0, 0, 0);
+      const int j = jt * 16 + r;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = it * 16 + 4 * q + reg;
+        if (i < h * kD && j < QW) slab[((size_t)i * QW + j) * L + l] = acc[reg];
+      }
+    }
+  }
+  if (stamp) {
+    ts[6] = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 6; ++i) p.stamps[i] = (double)(ts[i + 1] - ts[i]);
+    p.stamps[6] = (double)(ts[7] - ts[3]);
+  }
+}
+
+static bool wide_use_mfma() {
+  static const int v = [] { const char *e = getenv("TNML_WIDE"); return (e && e[0] == 'v' && e[1] == '1') ? 0 : 1; }();
+  return v != 0;
+}
+
 void launch_wide(const WideParams &p, int nblk, hipStream_t st) {
+  if (wide_use_mfma()) {
+    WideMfmaDims dm = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
+    const size_t lds = wide_mfma_carve(nullptr, dm, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
+    if (lds <= 160 * 1024) {
+      hipLaunchKernelGGL(wide_step_mfma_kernel, dim3(nblk), dim3(kMfmaThreads), lds, st, p);
+      return;
+    }
+  }
   const int hmax = p.h > p.hp ? p.h : p.hp;
   const int gmax = p.g > p.gp ? p.g : p.gp;
   const int core_elems = p.do_ext ? p.ext_core.n_in * kD * p.ext_core.n_out : 0;

@@ -183,7 +183,7 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   c->metrics_cap = N;
   HIP_TRY(hipMalloc(&c->metrics, (size_t)c->metrics_cap * 2 * sizeof(float)));
   HIP_TRY(hipMalloc(&c->scal, 64 * sizeof(float)));
-  c->dbg_elems = 4 * c->bmax + 64 + 24;   // 4 tensors, sigma[64], 5 scalars, 9 stamps
+  c->dbg_elems = 4 * c->bmax + 64 + 32;   // 4 tensors, sigma[64], 5 scalars, 9 stamps
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
   HIP_TRY(hipMalloc(&c->status, sizeof(int)));
   HIP_TRY(hipMemsetAsync(c->status, 0, sizeof(int), c->stream));
@@ -683,6 +683,7 @@ extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_s
       const int gs = left_dir ? p - 1 : p + 2;
       w.Gcur = (gs >= 0 && gs <= N - 1) ? c->env_slot(ahe, gs) : nullptr;
     }
+    w.stamps = c->stamps ? c->dbg + 4 * c->bmax + 64 + 5 + 17 : nullptr;
     prof_begin(c);
     launch_wide(w, nblk, c->stream);
     prof_end(c, 1);
@@ -813,9 +814,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
   if (c->last_bsize <= 0) return fail(TNML_ERR_STATE, "no step has run yet");
   HIP_TRY(hipSetDevice(c->device));
   const size_t Bs = c->last_bsize;
-  std::vector<double> hbuf(4 * Bs + 64 + 24);   // tensors, sigma, 5 scalars, 14 stamps
+  std::vector<double> hbuf(4 * Bs + 64 + 32);   // tensors, sigma, 5 scalars, 14 stamps
   HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, (4 * Bs + 64 + 5) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + 64 + 5, c->dbg + 4 * c->bmax + 64 + 5, 17 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + 64 + 5, c->dbg + 4 * c->bmax + 64 + 5, 24 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   auto tensor_out = [&](size_t block) -> int {
     if (capacity < Bs) return fail(TNML_ERR_ARG, "capacity too small");
@@ -843,9 +844,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
       if (n_out) *n_out = c->last_n;
       return TNML_OK;
     case TNML_DBG_L2:
-      if (capacity < 22) return fail(TNML_ERR_ARG, "capacity too small");
-      memcpy(out, hbuf.data() + 4 * Bs + 64, 22 * sizeof(double));
-      if (n_out) *n_out = 22;
+      if (capacity < 29) return fail(TNML_ERR_ARG, "capacity too small");
+      memcpy(out, hbuf.data() + 4 * Bs + 64, 29 * sizeof(double));
+      if (n_out) *n_out = 29;
       return TNML_OK;
   }
   return fail(TNML_ERR_ARG, "unknown debug selector %d", what);

@@ -57,6 +57,7 @@ struct WideParams {
   float *slabs;        // [nblk][slab_stride]
   int slab_stride;
   int bsize;           // h*D*D*g*L
+  double *stamps;      // diagnostic cycle stamps of workgroup 0 (nullptr normally)
 };
 
 struct NarrowParams {

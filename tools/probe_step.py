@@ -35,6 +35,8 @@ def stamp_line(tag, sc):
         print('   pre split: load %d / B %d / L2 %d / sums+update %d / gram %d cycles' % tuple(sc[14:19]))
     if len(sc) > 21:
         print('   one round, parameter wave: loads+new elements %d / rotation %d / stores+barrier %d cycles' % tuple(sc[19:22]))
+    if len(sc) > 28:
+        print('   wide kernel WG0: x-stage %d / operand stage %d / f+env MFMA %d / activation %d / gP %d / dB MFMA+store %d cycles (own activation %d)' % tuple(sc[22:29]))
     if len(sc) > 13:
         print('   post split: sort %d / cores %d / norm env + metrics %d cycles' % (sc[11], sc[12], sc[13]))
 
