@@ -393,9 +393,6 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 
   int cur = 0;
   if (p.stamps && tid == 0) t_c1 = __builtin_amdgcn_s_memtime();
-  // the parameter wave's dependent chain is the critical path of every round: let it win the
-  // arbitration for issue slots and LDS against the worker waves of its SIMD
-  if (__builtin_amdgcn_readfirstlane(tid) < T0) __builtin_amdgcn_s_setprio(3);
   if (n > 1) {
     double kept2 = kept_scale(Gc);
     if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
@@ -506,7 +503,6 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     converged = 1;
   }
   double *V = Vc;
-  if (__builtin_amdgcn_readfirstlane(tid) < T0) __builtin_amdgcn_s_setprio(0);
   if (p.stamps && tid == 0) t_c2 = __builtin_amdgcn_s_memtime();
 
   // ---- phase 8: eigenvalues = diag(G), descending order -------------------------------------------

@@ -457,9 +457,10 @@ __host__ __device__ inline WideMfmaSmem wide_mfma_carve(float *base, WideMfmaDim
   w.sPg = q; q += (size_t)L * d.I3 * kTSP;           // g[l][s] P[i][s]
   w.sQ = q; q += d.J3 * kTSP;                        // Q[j][s]
   // raw landing zones of the asynchronous global -> LDS loads (64 floats per wave-instruction)
-  w.rH = q; q += up(hp, 2) * kTS;                    // H' rows   [h'][s]
-  w.rGp = q; q += up(gp, 2) * kTS;                   // G' rows   [g'][s]
-  w.rG = q; q += up(g, 2) * kTS;                     // G rows    [g][s]
+  constexpr int RPI = 64 / kTS;                      // sample rows per wave-instruction
+  w.rH = q; q += up(hp, RPI) * kTS;                  // H' rows   [h'][s]
+  w.rGp = q; q += up(gp, RPI) * kTS;                 // G' rows   [g'][s]
+  w.rG = q; q += up(g, RPI) * kTS;                   // G rows    [g][s]
   w.rB = q; q += up(hp * kD * kD * gp * L, 64);      // B' as stored
   w.rA = q; q += up(hp * kD * h, 64);                // extension core A[i][hn], unpadded
   w.floats = (size_t)(q - base);
@@ -489,23 +490,26 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_kernel(WideParams
   typedef __attribute__((address_space(3))) void *lptr_t;
 #define GLDS(gp_, lp_) __builtin_amdgcn_global_load_lds((gptr_t)(gp_), (lptr_t)(lp_), 4, 0, 0)
   const int NWV = NT / 64;
-  const int half = lane >> 5, col = lane & 31;
+  static_assert(kTS == 32 || kTS == 64, "a wave-instruction carries 64 / kTS whole sample rows");
+  constexpr int RPI = 64 / kTS;
+  const int half = lane / kTS, col = lane % kTS;
   const bool haveH = p.Hprev && !p.first_ext && (p.do_f || p.do_ext);
   {
     // x of the three sites: 3 * kTS * kD = 192 floats = 3 wave-instructions
-    if (wave < 3) {
-      const float *src = wave == 0 ? p.x_km1 : (wave == 1 ? p.x_k : p.x_kp1);
-      if (src) GLDS(src + (size_t)s0 * kD + lane, w.sX + wave * 64);
+    for (int c = wave; c < 3 * kTS * kD / 64; c += NWV) {     // x of the three sites, kTS * kD floats each
+      const int which = c / (kTS * kD / 64), off = (c % (kTS * kD / 64)) * 64;
+      const float *src = which == 0 ? p.x_km1 : (which == 1 ? p.x_k : p.x_kp1);
+      if (src) GLDS(src + (size_t)s0 * kD + off + lane, w.sX + c * 64);
     }
     if (haveH)
-      for (int pr = wave; pr < up(hp, 2) / 2; pr += NWV)
-        GLDS(p.Hprev + (size_t)min(2 * pr + half, hp - 1) * p.b_pad + s0 + col, w.rH + pr * 64);
+      for (int pr = wave; pr < up(hp, RPI) / RPI; pr += NWV)
+        GLDS(p.Hprev + (size_t)min(RPI * pr + half, hp - 1) * p.b_pad + s0 + col, w.rH + pr * 64);
     if (p.do_f && p.Gprev)
-      for (int pr = wave; pr < up(gp, 2) / 2; pr += NWV)
-        GLDS(p.Gprev + (size_t)min(2 * pr + half, gp - 1) * p.b_pad + s0 + col, w.rGp + pr * 64);
+      for (int pr = wave; pr < up(gp, RPI) / RPI; pr += NWV)
+        GLDS(p.Gprev + (size_t)min(RPI * pr + half, gp - 1) * p.b_pad + s0 + col, w.rGp + pr * 64);
     if (p.Gcur)
-      for (int pr = wave; pr < up(g, 2) / 2; pr += NWV)
-        GLDS(p.Gcur + (size_t)min(2 * pr + half, g - 1) * p.b_pad + s0 + col, w.rG + pr * 64);
+      for (int pr = wave; pr < up(g, RPI) / RPI; pr += NWV)
+        GLDS(p.Gcur + (size_t)min(RPI * pr + half, g - 1) * p.b_pad + s0 + col, w.rG + pr * 64);
     if (p.do_f) {
       const int nB = nI * nJ * L;
       for (int c = wave; c < up(nB, 64) / 64; c += NWV) GLDS(p.Bprev + min(c * 64 + lane, nB - 1), w.rB + c * 64);

@@ -240,7 +240,9 @@ extern "C" int tnml_comm_init(tnml_ctx *c, int rank, int nranks, const void *uid
   HIP_TRY(hipSetDevice(c->device));
   c->rank = rank;
   c->nranks = nranks;
-  if (nranks == 1) return TNML_OK;
+  // a 1-rank communicator is pointless in production; TNML_FORCE_COMM=1 creates it anyway so that the
+  // RCCL code path (init + per-step all-reduce on the context's stream) can be exercised on one GPU
+  if (nranks == 1 && !(getenv("TNML_FORCE_COMM") && atoi(getenv("TNML_FORCE_COMM")))) return TNML_OK;
   ncclUniqueId id;
   memcpy(&id, uid128, sizeof id);
   NCCL_TRY(ncclCommInitRank(&c->comm, nranks, id, rank));

@@ -222,3 +222,30 @@ def test_errors_mirror_reference():
         ctx.forward()
     assert ei.value.code == -2
     ctx.close()
+
+
+def test_rccl_path_single_rank(monkeypatch):
+    """The per-step all-reduce is an RCCL call issued by the library between the reduce and the
+    update kernels.  With one GPU only a 1-rank communicator can be built (TNML_FORCE_COMM=1), which
+    still exercises ncclCommInitRank, the max all-reduce of the calibration and 2(N-1) sum
+    all-reduces on the context's stream; the result must equal the communicator-free run."""
+    from tensornetworkforml_amd import dist as tdist
+    d = gu.load('traj_fixed_N16_script')
+    N, M, L, D = int(d['N']), int(d['M']), int(d['L']), int(d['D'])
+    kw = _kw(d)
+    outs = []
+    for force in ('0', '1'):
+        monkeypatch.setenv('TNML_FORCE_COMM', force)
+        ctx = make_ctx(N, D, L, M, gu.indexed(d, 'init_core', N), 0, d['X'], d['y'])
+        tdist.attach_comm(ctx, 0, 1)
+        lmax = ctx.forward_logabsmax()
+        ctx.forward()
+        met, f = ctx.sweep(False, N - 1, True, kw['lr'], kw['weight_dec'], kw['L2_flag'], kw['act_fn'], kw['loss_fn'],
+                           kw['T'], kw['trunc'])
+        ctx.forward()
+        met2, f2 = ctx.sweep(True, N - 1, True, kw['lr'], kw['weight_dec'], kw['L2_flag'], kw['act_fn'], kw['loss_fn'],
+                             kw['T'], kw['trunc'])
+        outs.append((lmax, met, f, met2, f2))
+        ctx.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
