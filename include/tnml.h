@@ -126,6 +126,22 @@ int tnml_sweep(tnml_ctx *ctx, int left_dir, int n_steps, int first_of_sweep, flo
                float weight_dec, int l2_flag, int act_fn, int loss_fn, float T, int trunc_policy,
                float *metrics_out, float *f_out);
 
+/* The three sub-steps the reference also exposes as methods, as standalone device calls (the same
+ * kernels as tnml_sweep, run in "stop after the update" / "given merged tensor" modes).
+ *   tnml_update_B   Network.update_B (Network_class.py:577-763): extends the behind environment,
+ *                   returns the updated merged tensor of sites (p, p+1), p = l_pos (- 1 when left_dir);
+ *                   B_canon [ml][D][D][mr][L] or NULL (= product of the two cores); cores, bonds and
+ *                   l_pos are left untouched; metrics2 = (accuracy, MAE) or NULL.
+ *   tnml_l2_term    Network.compute_L2_reg (:966-1179): loss = wd <B, Ln.B.Rn>, grad = 2 wd Ln.B.Rn.
+ *   tnml_svd_split  Network.tensor_svd (:839-962): U sqrt(S) [rows][m] and sqrt(S) Vh [m][cols] of a
+ *                   rows x cols matrix (both multiples of D, min <= 64), sigma[min(rows, cols)] or NULL. */
+int tnml_update_B(tnml_ctx *ctx, const float *B_canon, int left_dir, float lr, float weight_dec, int l2_flag,
+                  int act_fn, int loss_fn, float T, double *Bnew_canon, size_t capacity, float *metrics2);
+int tnml_l2_term(tnml_ctx *ctx, const float *B_canon, int left_dir, float weight_dec, double *loss,
+                 double *grad_canon, size_t capacity);
+int tnml_svd_split(tnml_ctx *ctx, const float *mat, int rows, int cols, int m, float *US, float *SVh,
+                   double *sigma);
+
 /* Network.apply_act_func / compute_loss_derivate on the device-resident f (:767-835);
  * act_out, lossder_out [L][b], either may be NULL.  input_is_activated != 0: f already went
  * through the activation (what compute_loss_derivate receives, :800), only the derivative runs. */

@@ -481,20 +481,118 @@ class Network():
         return Tensor(elem=d.astype(np.float64), axes_names=['l', 'b'])
 
     def tensor_svd(self, T, left_dir=False, threshold=0.999):
-        """SVD split of a 2-D Tensor with sqrt(S) on both factors (Network_class.py:839-962), run by
-        the device's Jacobi kernel.  The rank kept follows `self.trunc` at the current l_pos."""
+        """SVD split of a 2-D Tensor ('i', 'j') with sqrt(S) on both factors (Network_class.py:839-962),
+        run by the device's Jacobi kernel.  The rank kept follows `self.trunc` at the current l_pos:
+        'reference' keeps all singular values next to the chain ends and `aggregations['i']['left']`
+        of them elsewhere (:894-945, `threshold` is computed but unused there); 'fixed' keeps
+        min(M, len(S))."""
         if type(T) != Tensor:
             raise TypeError("This function only support object from the class Tensor")
         if len(T.shape) != 2:
             raise ValueError("This function only support a 2D tensors")
-        raise NotImplementedError("standalone tensor_svd is fused into sweep_step on the device "
-                                  "(tnml_sweep); it is not exposed as a separate device call yet")
+        rows, cols = T.elem.shape
+        nS = min(rows, cols)
+        lp = self.l_pos
+        if self.trunc == 'fixed':
+            m = min(self.M, nS)
+        else:
+            interior = (1 < lp < self.N - 1) if left_dir else (0 < lp < self.N - 2)
+            m = int(T.aggregations['i']['left']) if interior else nS
+            if m > nS:
+                # np.eye(m, m) * S[:m] in the reference (:914 / :949)
+                raise ValueError("operands could not be broadcast together with shapes (%d,%d) (%d,) " % (m, m, nS))
+        ctx = self._sync_to_device()
+        US, SVh, _ = ctx.svd_split(np.asarray(T.elem, dtype=np.float32), m)
+        TU = Tensor(elem=US.astype(np.float64), axes_names=['i', 'right'])
+        TSVh = Tensor(elem=SVh.astype(np.float64), axes_names=['left', 'j'])
+        TU.aggregations['i'] = T.aggregations['i']
+        TSVh.aggregations['j'] = T.aggregations['j']
+        TU.disaggregate('i')
+        TSVh.disaggregate('j')
+        return TU, TSVh
+
+    def _merged_to_canonical(self, B, p):
+        """Named merged Tensor on sites (p, p+1) -> (array (ml, D, D, mr, L), function mapping a canonical
+        array back to a Tensor with B's own axis order)."""
+        names = [str(a) for a in B.axes_names]
+        want = ['left', 'd%d' % p, 'd%d' % (p + 1), 'right', 'l']
+        for n in names:
+            if n not in want:
+                raise ValueError("axis '%s' does not belong to the merged tensor of sites (%d, %d)" % (n, p, p + 1))
+        present = [n for n in want if n in names]
+        arr = np.transpose(np.asarray(B.elem), [names.index(n) for n in present])
+        full_shape = [arr.shape[present.index(n)] if n in present else 1 for n in want]
+        canon = np.ascontiguousarray(arr.reshape(full_shape), dtype=np.float32)
+
+        def back(c):
+            t = np.asarray(c, dtype=np.float64).reshape([full_shape[want.index(n)] for n in present])
+            return Tensor(elem=np.transpose(t, [present.index(n) for n in names]).copy(), axes_names=list(B.axes_names))
+        return canon, back
 
     def update_B(self, B, f_orig, y, lr, weight_dec, L2_flag=True, ldf=0, var_hist=None, debug=False):
-        raise NotImplementedError("update_B is fused into sweep_step on the device (tnml_sweep)")
+        """Gradient step on the merged tensor B of sites (l-ldf, l+1-ldf) (Network_class.py:577-763):
+        extends the environment list behind the sweep, builds dB = sum_b loss'(f_b) phi_b, subtracts
+        the L2 / weight-decay term, clips by the L1 ratio and returns B + lr dB.  `forward(X)` must
+        have built the environments for this batch; cores and l_pos are left as they are."""
+        left_dir = bool(ldf)
+        l = self.l_pos
+        if left_dir and not (1 <= l <= self.N - 1):
+            raise Exception('### Error ###\n l =', l, ' -> position not allowed for left sweep step')
+        if not left_dir and not (0 <= l <= self.N - 2):
+            raise Exception('### Error ###\n l =', l, ' -> position not allowed for right sweep step')
+        p = l - int(left_dir)
+        canon, back = self._merged_to_canonical(B, p)
+        y = np.asarray(y)
+        y_int = np.argmax(y, axis=0) if y.ndim == 2 else y
+        ctx = self._sync_to_device()
+        self._upload_labels(y_int)
+        fnames = [str(a) for a in f_orig.axes_names]
+        f32 = np.asarray(f_orig.elem if fnames[0] == 'l' else f_orig.elem.T, dtype=np.float32)
+        ctx.set_f(f32)
+        if self._first_of_sweep(left_dir):
+            if left_dir:
+                self._r_entries, self._r_user = [], None
+            else:
+                self._l_entries, self._l_user = [], None
+        Bnew, met = ctx.update_B(canon, left_dir, lr, weight_dec, L2_flag, self.act_fn, self.loss_fn, self.T)
+        if var_hist is not None:
+            if debug:
+                ctx.debug_enable(True)
+                Bd, dB, L2g = ctx.step_debug('B'), ctx.step_debug('dB_raw'), ctx.step_debug('L2_grad')
+                sc = ctx.step_debug('scalars')
+                ctx.debug_enable(False)
+                var_hist[0].append(np.abs(Bd).mean())
+                var_hist[1].append(np.abs(dB - L2g).mean())
+                var_hist[2].append(float(met[0]))
+                var_hist[3].append(np.abs(f32).mean())
+                var_hist[4].append(float(met[1]))
+                var_hist[5].append(sc[0] if L2_flag else None)
+                var_hist[6].append(np.abs(L2g).mean())
+            else:
+                var_hist[0].append(float(met[0]))
+                var_hist[1].append(float(met[1]))
+        self._env_epoch += 1
+        S_R, S_L = _hip.SIDE_RIGHT, _hip.SIDE_LEFT
+        if left_dir:
+            self._r_entries = [('env', S_R, i) for i in range(self.N - 1, l, -1)]
+        else:
+            self._l_entries = [('env', S_L, i) for i in range(0, l)]
+        return back(Bnew)
 
     def compute_L2_reg(self, B, weight_dec=0.001, left_dir=False):
-        raise NotImplementedError("compute_L2_reg is fused into sweep_step on the device (tnml_sweep)")
+        """L2 term of the loss, weight_dec * <psi|psi> with B in place of the two cores at
+        (l-ldf, l+1-ldf), and its gradient w.r.t. B (Network_class.py:966-1179).  Returns
+        (float, Tensor shaped like B)."""
+        left_dir = bool(left_dir)
+        l = self.l_pos
+        p = l - int(left_dir)
+        if p < 0 or p > self.N - 2:
+            raise Exception('### Error ###\n l =', l, ' -> position not allowed for %s sweep step'
+                            % ('left' if left_dir else 'right'))
+        canon, back = self._merged_to_canonical(B, p)
+        ctx = self._sync_to_device()
+        loss, grad = ctx.l2_term(canon, left_dir, weight_dec)
+        return loss, back(grad)
 
     # ------------------------------------------------------------------------------------------
     # persistence: the whole object is pickled (training_diagonals.py:69-70)

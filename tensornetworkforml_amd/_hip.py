@@ -26,6 +26,7 @@ SYMBOLS = [
     'tnml_set_f', 'tnml_get_f', 'tnml_sweep', 'tnml_activation', 'tnml_get_env', 'tnml_debug_enable',
     'tnml_get_step_debug', 'tnml_l_pos', 'tnml_batch', 'tnml_timer_start', 'tnml_timer_stop',
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
+    'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split',
 ]
 
 
@@ -82,6 +83,10 @@ def lib():
         L.tnml_profile_reset.argtypes = [vp]
         L.tnml_svd_stats.argtypes = [vp, C.c_int, f64p]
         L.tnml_trunc_rank.argtypes = [C.c_int] * 9
+        L.tnml_update_B.argtypes = [vp, f32p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    f64p, C.c_size_t, f32p]
+        L.tnml_l2_term.argtypes = [vp, f32p, C.c_int, C.c_float, f64p, f64p, C.c_size_t]
+        L.tnml_svd_split.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f64p]
         _lib = L
     return _lib
 
@@ -228,6 +233,43 @@ class Context:
                               TRUNC[trunc], _ptr(met, C.c_float) if want_metrics else None,
                               _ptr(f, C.c_float) if want_f else None))
         return met, f
+
+    def update_B(self, B, left_dir, lr, weight_dec, L2_flag, act_fn, loss_fn, T):
+        """Updated merged tensor of the two sites at l_pos (canonical (ml, D, D, mr, L)) and the step's
+        (accuracy, MAE); B = None uses the product of the two cores."""
+        shape = None
+        bp = None
+        if B is not None:
+            B = _f32(B)
+            shape = B.shape
+            bp = _ptr(B, C.c_float)
+        cap = 4 * max(self.M, self.D * self.L) ** 2 * self.D * self.D * self.L
+        out = np.empty(cap, dtype=np.float64)
+        met = np.empty(2, dtype=np.float32)
+        _chk(lib().tnml_update_B(self._h, bp, int(bool(left_dir)), float(lr), float(weight_dec), int(bool(L2_flag)),
+                                 ACT[act_fn], LOSS[loss_fn], float(T), _ptr(out, C.c_double), out.size,
+                                 _ptr(met, C.c_float)))
+        return (out[:int(np.prod(shape))].reshape(shape).copy() if shape is not None else out), met
+
+    def l2_term(self, B, left_dir, weight_dec):
+        """(wd <B, Ln.B.Rn>, 2 wd Ln.B.Rn) for a merged tensor B (canonical layout) at l_pos."""
+        B = _f32(B)
+        grad = np.empty(B.size, dtype=np.float64)
+        loss = C.c_double()
+        _chk(lib().tnml_l2_term(self._h, _ptr(B, C.c_float), int(bool(left_dir)), float(weight_dec), C.byref(loss),
+                                _ptr(grad, C.c_double), grad.size))
+        return loss.value, grad.reshape(B.shape)
+
+    def svd_split(self, mat, m):
+        """(U sqrt(S) [rows, m], sqrt(S) Vh [m, cols], all singular values) of a 2-D matrix."""
+        mat = _f32(mat)
+        rows, cols = mat.shape
+        US = np.empty((rows, int(m)), dtype=np.float32)
+        SVh = np.empty((int(m), cols), dtype=np.float32)
+        sig = np.empty(min(rows, cols), dtype=np.float64)
+        _chk(lib().tnml_svd_split(self._h, _ptr(mat, C.c_float), rows, cols, int(m), _ptr(US, C.c_float),
+                                  _ptr(SVh, C.c_float), _ptr(sig, C.c_double)))
+        return US, SVh, sig
 
     def activation(self, act_fn, loss_fn, T, want_act=True, want_der=False, input_is_activated=False):
         a = np.empty((self.L, self.b), dtype=np.float32) if want_act else None

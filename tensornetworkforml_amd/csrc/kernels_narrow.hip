@@ -132,7 +132,7 @@ __device__ inline void small_gemm_f64(int nbatch, int M, int N, int K, FA loadA,
 }
 
 struct NarrowCarve {
-  double *dT, *dG, *Z, *dNh, *dNg, *dLam, *dRed, *dT2, *dCS;
+  double *dT, *dG, *Z, *dNh, *dNg, *dLam, *dRed, *dT2, *dCS, *dSq;
   float *fB, *fBp, *sLab, *sPl, *sCb;
   int *sOrd, *sFlag, *sPi, *sPiInv;
   size_t bytes;
@@ -154,6 +154,7 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
   k.dRed = d; d += 64;
   k.dT2 = d; d += (size_t)h * D * m;
   k.dCS = d; d += 4 * ne;                   // (c, s, t, -) per pair, two rounds in flight
+  k.dSq = d; d += 2 * ne;                   // sigma^(1/2) and sigma^(-1/2) of the kept columns
   float *f = (float *)d;
   k.fB = f; f += Bs;
   k.fBp = f; f += Bs + (size_t)(D * h < D * g * L ? D * h : D * g * L) + 4;   // rows at stride (cols + 1): bank-conflict-free
@@ -189,16 +190,20 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 #define TNML_STAMP(i) if (p.stamps && tid == 0) t_p[i] = __builtin_amdgcn_s_memtime()
   if (p.stamps && tid == 0) { t_c0 = __builtin_amdgcn_s_memtime(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
   // ---- phase 0: stage the two cores and the norm environments ---------------------------------
-  for (int e = tid; e < h * D * s * L; e += NT) {
-    const int l = e % L, q = e / L;
-    const int s_ = q % s, q2 = q / s;
-    const int d = q2 % D, h_ = q2 / D;
-    k.sLab[e] = p.lab.base[h_ * p.lab.s_in + d * p.lab.s_d + s_ * p.lab.s_out + l];
-  }
-  for (int e = tid; e < s * D * g; e += NT) {
-    const int g_ = e % g, q = e / g;
-    const int d = q % D, s_ = q / D;
-    k.sPl[e] = p.pl.base[s_ * p.pl.s_in + d * p.pl.s_d + g_ * p.pl.s_out];
+  if (!p.Bdirect) {
+    for (int e = tid; e < h * D * s * L; e += NT) {
+      const int l = e % L, q = e / L;
+      const int s_ = q % s, q2 = q / s;
+      const int d = q2 % D, h_ = q2 / D;
+      k.sLab[e] = p.lab.base[h_ * p.lab.s_in + d * p.lab.s_d + s_ * p.lab.s_out + l];
+    }
+    for (int e = tid; e < s * D * g; e += NT) {
+      const int g_ = e % g, q = e / g;
+      const int d = q % D, s_ = q / D;
+      k.sPl[e] = p.pl.base[s_ * p.pl.s_in + d * p.pl.s_d + g_ * p.pl.s_out];
+    }
+  } else {
+    for (int e = tid; e < Bs; e += NT) k.fB[e] = p.Bdirect[e];
   }
   for (int e = tid; e < h * h; e += NT) k.dNh[e] = p.Nh ? p.Nh[e] : 1.0;
   for (int e = tid; e < g * g; e += NT) k.dNg[e] = p.Ng ? p.Ng[e] : 1.0;
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   TNML_STAMP(0);
   // ---- phase 1: B[h,dk,dk1,g,l] = sum_s lab(h,dk,s,l) * pl(s,dk1,g) ---------------------------
   const int RW = D * D * g * L;  // elements per behind-bond index
-  {   // rows i = (h_, dk, l), columns j = (dk1, g_), inner index the shared bond
+  if (!p.Bdirect) {   // rows i = (h_, dk, l), columns j = (dk1, g_), inner index the shared bond
     const int QW = D * g;
     small_gemm_f64(L, h * D, QW, s,
                    [&](int l, int i, int kk) { return (double)k.sLab[(i * s + kk) * L + l]; },
@@ -261,13 +266,15 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   double factor = (double)p.lr;
   if (sumD > sumB) factor = (double)p.lr * (sumB / sumD);
   const bool bad = !isfinite(sumD) || !isfinite(sumB);
-  for (int e = tid; e < Bs; e += NT) {
-    const float v = (float)((double)k.fB[e] + factor * k.dG[e]);
-    k.fB[e] = v;
-    k.fBp[e + e / c] = v;                 // row e / c starts at (e / c) * (c + 1)
-    p.Bnew[e] = v;
-    if (p.dbg) p.dbg[2 * (size_t)Bs + e] = (double)v;
-  }
+  for (int row = tid >> 6; row < r; row += NT >> 6)       // rows over waves, columns over lanes
+    for (int x = tid & 63; x < c; x += 64) {
+      const int e = row * c + x;
+      const float v = (float)((double)k.fB[e] + factor * k.dG[e]);
+      k.fB[e] = v;
+      k.fBp[row * (c + 1) + x] = v;
+      p.Bnew[e] = v;
+      if (p.dbg) p.dbg[2 * (size_t)Bs + e] = (double)v;
+    }
   if (tid == 0) {
     if (bad) atomicOr(p.status, 1);
     if (p.dbg) {
@@ -278,6 +285,15 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     }
   }
   __syncthreads();   // dT/dG are dead from here on; Z aliases them
+  if (p.stop_after_update) {                       // standalone update_B / compute_L2_reg
+    if (tid == 0 && p.metrics) {
+      const double cnt = (double)p.red[Bs + 3];
+      const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
+      p.metrics[0] = (float)((double)p.red[Bs] * inv);
+      p.metrics[1] = (float)((double)p.red[Bs + 1] * inv / (double)L);
+    }
+    return;
+  }
 
   TNML_STAMP(3);
   // ---- phase 6: Gram matrix in float64 (padded to ne x ne with a zero row/column), V = I ----------
@@ -537,13 +553,19 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   if (p.stamps && tid == 0) t_c2b = __builtin_amdgcn_s_memtime();
   // ---- phase 9: the two new cores -----------------------------------------------------------------
   const double lam_max = k.dLam[k.sOrd[0]];
-  // short-side factor: q_j * sigma_j^(1/2)
-  for (int e = tid; e < n * m; e += NT) {
-    const int sp = e % m, kk = e / m;
+  for (int sp = tid; sp < m; sp += NT) {                 // sigma^(+-1/2) once per kept column (lam = sigma^2)
+    const double lam = k.dLam[k.sOrd[sp]];
+    const bool ok = lam > 1e-300 && lam > 1e-30 * lam_max;
+    const double sq = ok ? sqrt(sqrt(lam)) : 0.0;
+    k.dSq[sp] = sq;
+    k.dSq[ne + sp] = ok ? 1.0 / sq : 0.0;
+  }
+  __syncthreads();
+  // short-side factor: q_j * sigma_j^(1/2)   (rows kk over waves, kept columns over lanes: no divisions)
+  for (int kk = tid >> 6; kk < n; kk += NT >> 6)
+   for (int sp = tid & 63; sp < m; sp += 64) {
     const int j = k.sOrd[sp];
-    const double lam = k.dLam[j];
-    const double sq = (lam > 1e-300 && lam > 1e-30 * lam_max) ? sqrt(sqrt(lam)) : 0.0;
-    const float v = (float)(V[(size_t)kk * ne + j] * sq);
+    const float v = (float)(V[kk * ne + j] * k.dSq[sp]);
     if (short_rows) {                       // kk = row index i = h_*D + dk  -> behind core
       k.sCb[kk * m + sp] = v;
       p.out_behind[(kk / D) * p.ob_s_h + (kk % D) * p.ob_s_d + sp * p.ob_s_m] = v;
@@ -551,7 +573,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
       const int l = kk % L, q = kk / L;
       p.out_ahead[sp * p.oa_s_m + (q / g) * p.oa_s_d + (q % g) * p.oa_s_g + l] = v;
     }
-  }
+   }
   // long-side factor: (W q_j) / sigma_j^(1/2); columns s', inner index the short one
   if (short_rows) {
     // long index = ahead group x = (dk1, g_, l) = qq * L + l: the label is the batch, rows are qq = (dk1, g_)
@@ -559,10 +581,8 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
                    [&](int l, int qq, int kk) { return (double)k.fB[kk * c + qq * L + l]; },
                    [&](int l, int kk, int sp) { return V[kk * ne + k.sOrd[sp]]; },
                    [&](int l, int qq, int sp, double acc) {
-                     const double lam = k.dLam[k.sOrd[sp]];
-                     const double isq = (lam > 1e-300 && lam > 1e-30 * lam_max) ? 1.0 / sqrt(sqrt(lam)) : 0.0;
                      const int dk1 = qq >= g ? 1 : 0;                     // D == 2
-                     p.out_ahead[sp * p.oa_s_m + dk1 * p.oa_s_d + (qq - dk1 * g) * p.oa_s_g + l] = (float)(acc * isq);
+                     p.out_ahead[sp * p.oa_s_m + dk1 * p.oa_s_d + (qq - dk1 * g) * p.oa_s_g + l] = (float)(acc * k.dSq[ne + sp]);
                    });
   } else {
     // long index = behind group x = (h_, dk) = h_ * D + dk: dk is the batch, rows are h_
@@ -570,9 +590,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
                    [&](int dk, int h_, int kk) { return (double)k.fBp[(h_ * D + dk) * (c + 1) + kk]; },
                    [&](int dk, int kk, int sp) { return V[kk * ne + k.sOrd[sp]]; },
                    [&](int dk, int h_, int sp, double acc) {
-                     const double lam = k.dLam[k.sOrd[sp]];
-                     const double isq = (lam > 1e-300 && lam > 1e-30 * lam_max) ? 1.0 / sqrt(sqrt(lam)) : 0.0;
-                     const float v = (float)(acc * isq);
+                     const float v = (float)(acc * k.dSq[ne + sp]);
                      k.sCb[(h_ * D + dk) * m + sp] = v;
                      p.out_behind[h_ * p.ob_s_h + dk * p.ob_s_d + sp * p.ob_s_m] = v;
                    });

@@ -72,6 +72,7 @@ struct tnml_ctx {
   int lab_cur = 0;
   double *Ln = nullptr, *Rn = nullptr;
   float *Bnew = nullptr, *slabs = nullptr, *red = nullptr, *metrics = nullptr, *scal = nullptr;
+  float *Bscr = nullptr, *Bscr2 = nullptr;   // scratch merged tensors of the standalone entry points
   int slab_stride = 0, nblk_cap = 0, metrics_cap = 0;
   double *dbg = nullptr;
   size_t dbg_elems = 0;
@@ -179,6 +180,8 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipMalloc(&c->Ln, (size_t)N * Mmax * Mmax * sizeof(double)));
   HIP_TRY(hipMalloc(&c->Rn, (size_t)N * Mmax * Mmax * sizeof(double)));
   HIP_TRY(hipMalloc(&c->Bnew, c->bmax * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->Bscr, c->bmax * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->Bscr2, c->bmax * sizeof(float)));
   HIP_TRY(hipMalloc(&c->red, (size_t)c->slab_stride * sizeof(float)));
   c->metrics_cap = N;
   HIP_TRY(hipMalloc(&c->metrics, (size_t)c->metrics_cap * 2 * sizeof(float)));
@@ -204,7 +207,7 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
   void *ptrs[] = {c->X, c->Xstage, c->y, c->f, c->ftmp, c->ftmp2, c->Lenv, c->Renv, c->cores, c->lab[0], c->lab[1],
-                  c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters};
+                  c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -589,9 +592,13 @@ static void fill_prev_operands(tnml_ctx *c, WideParams &w, int left_dir, int p_p
   w.Bprev = c->Bnew;
 }
 
-extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep, float lr, float weight_dec,
-                          int l2_flag, int act_fn, int loss_fn, float T, int trunc_policy, float *metrics_out,
-                          float *f_out) {
+// mode 0: n_steps full steps.  mode 1 (standalone update_B): ONE step up to and including the update of
+// the merged tensor -- the behind environment is extended and B_new lands in the debug block, but no
+// SVD runs and cores, bonds and l_pos stay as they are.  Bdirect_dev: merged tensor to use instead of
+// the product of the two cores (relative layout), or nullptr.
+static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep, float lr, float weight_dec,
+                      int l2_flag, int act_fn, int loss_fn, float T, int trunc_policy, float *metrics_out,
+                      float *f_out, int mode, const float *Bdirect_dev) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   if (!c->cores_set) return fail(TNML_ERR_STATE, "cores were never set");
   if (!c->have_input || !c->have_labels) return fail(TNML_ERR_STATE, "a sweep needs inputs and labels (tnml_set_input)");
@@ -723,7 +730,10 @@ extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_s
     n.out_behind = c->core_slot(sb);
     n.out_ahead = c->lab[c->lab_cur ^ 1];
     n.metrics = c->metrics + 2 * (size_t)step;
-    n.dbg = c->debug ? c->dbg : nullptr;
+    n.dbg = (c->debug || mode == 1) ? c->dbg : nullptr;
+    n.Bdirect = Bdirect_dev;
+    n.stop_after_update = mode == 1;
+    if (mode == 1) { n.Bnew = c->Bscr2; n.Nh_new = nullptr; }
     n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + 64 + 5 : nullptr;
     n.status = c->status;
     n.counters = c->counters;
@@ -733,6 +743,16 @@ extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_s
     {   // diagnostic: TNML_EXTRA_LAUNCHES=k adds k trivial dependent launches per step (prices a boundary)
       static const int extra = getenv("TNML_EXTRA_LAUNCHES") ? atoi(getenv("TNML_EXTRA_LAUNCHES")) : 0;
       for (int x = 0; x < extra; ++x) launch_scale(c->scal, 1, 1.0f, c->stream);
+    }
+    c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
+    if (mode == 1) {
+      // the behind environment list grew (as update_B does, Network_class.py:637-652); nothing else changes
+      HIP_TRY(hipGetLastError());
+      if (metrics_out) {
+        HIP_TRY(hipMemcpyAsync(metrics_out, c->metrics, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+      }
+      return TNML_OK;
     }
     // ---- bookkeeping ---------------------------------------------------------------------------
     c->bond[p] = m;
@@ -777,6 +797,154 @@ extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_s
       if (st & 1) return fail(TNML_ERR_NONFINITE, "non-finite values reached the bond update / SVD (status %d)", st);
       return fail(TNML_ERR_NONFINITE, "Jacobi SVD did not converge (status %d)", st);
     }
+  }
+  return TNML_OK;
+}
+
+extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep, float lr, float weight_dec,
+                          int l2_flag, int act_fn, int loss_fn, float T, int trunc_policy, float *metrics_out,
+                          float *f_out) {
+  return sweep_impl(c, left_dir, n_steps, first_of_sweep, lr, weight_dec, l2_flag, act_fn, loss_fn, T, trunc_policy,
+                    metrics_out, f_out, 0, nullptr);
+}
+
+// canonical (a, d, d', c, l) <-> sweep-relative (h, dk, dk1, g, l) layout of a merged tensor on sites (p, p+1)
+template <class Tsrc, class Tdst>
+static void canon_to_rel(const Tsrc *src, Tdst *dst, int left_dir, int ml, int mr, int D, int L) {
+  if (!left_dir) { for (size_t e = 0; e < (size_t)ml * D * D * mr * L; ++e) dst[e] = (Tdst)src[e]; return; }
+  const int h = mr, g = ml;      // behind = right, ahead = left
+  for (int h_ = 0; h_ < h; ++h_) for (int dk = 0; dk < D; ++dk) for (int dk1 = 0; dk1 < D; ++dk1)
+    for (int g_ = 0; g_ < g; ++g_) for (int l = 0; l < L; ++l)
+      dst[((((size_t)h_ * D + dk) * D + dk1) * g + g_) * L + l] = (Tdst)src[((((size_t)g_ * D + dk1) * D + dk) * h + h_) * L + l];
+}
+
+static int norm_envs_for_label_site(tnml_ctx *c) {
+  if (!c->Ln_valid) { int rc = build_norm_chain(c, false); if (rc) return rc; c->Ln_valid = true; }
+  if (!c->Rn_valid) { int rc = build_norm_chain(c, true); if (rc) return rc; c->Rn_valid = true; }
+  return TNML_OK;
+}
+
+extern "C" int tnml_update_B(tnml_ctx *c, const float *B_canon, int left_dir, float lr, float weight_dec, int l2_flag,
+                             int act_fn, int loss_fn, float T, double *Bnew_canon, size_t capacity, float *metrics2) {
+  if (!c || !Bnew_canon) return fail(TNML_ERR_ARG, "NULL argument");
+  left_dir = left_dir ? 1 : 0;
+  const int l = c->l_pos, p = left_dir ? l - 1 : l;
+  if (p < 0 || p > c->N - 2) return fail(TNML_ERR_STATE, "position not allowed for %s sweep step (l_pos = %d)", left_dir ? "left" : "right", l);
+  HIP_TRY(hipSetDevice(c->device));
+  const int ml = c->ml(p), mr = c->mr(p + 1);
+  const size_t bsize = (size_t)ml * c->D * c->D * mr * c->L;
+  if (capacity < bsize) return fail(TNML_ERR_ARG, "capacity too small");
+  const float *Bd = nullptr;
+  if (B_canon) {
+    std::vector<float> rel(bsize);
+    canon_to_rel(B_canon, rel.data(), left_dir, ml, mr, c->D, c->L);
+    HIP_TRY(hipMemcpyAsync(c->Bscr, rel.data(), bsize * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    Bd = c->Bscr;
+  }
+  if (l2_flag) { int rc = norm_envs_for_label_site(c); if (rc) return rc; }
+  const bool first = c->l_pos == (left_dir ? c->N - 1 : 0);
+  int rc = sweep_impl(c, left_dir, 1, first, lr, weight_dec, l2_flag, act_fn, loss_fn, T, TNML_TRUNC_FIXED, metrics2, nullptr,
+                      1, Bd);
+  if (rc) return rc;
+  size_t n = 0;
+  const bool dbg_was = c->debug;
+  c->debug = true;
+  rc = tnml_get_step_debug(c, TNML_DBG_B_NEW, Bnew_canon, capacity, &n);
+  c->debug = dbg_was;
+  return rc;
+}
+
+extern "C" int tnml_l2_term(tnml_ctx *c, const float *B_canon, int left_dir, float weight_dec, double *loss,
+                            double *grad_canon, size_t capacity) {
+  if (!c || !B_canon || !loss || !grad_canon) return fail(TNML_ERR_ARG, "NULL argument");
+  left_dir = left_dir ? 1 : 0;
+  const int l = c->l_pos, p = left_dir ? l - 1 : l;
+  if (p < 0 || p > c->N - 2) return fail(TNML_ERR_STATE, "no merged tensor at l_pos = %d for a %s step", l, left_dir ? "left" : "right");
+  if (!c->cores_set) return fail(TNML_ERR_STATE, "cores were never set");
+  HIP_TRY(hipSetDevice(c->device));
+  const int N = c->N, D = c->D, L = c->L;
+  const int ml = c->ml(p), mr = c->mr(p + 1);
+  const int h = left_dir ? mr : ml, g = left_dir ? ml : mr;
+  const size_t bsize = (size_t)ml * D * D * mr * L;
+  if (capacity < bsize) return fail(TNML_ERR_ARG, "capacity too small");
+  if (bsize > c->bmax) return fail(TNML_ERR_ARG, "merged tensor exceeds the buffers sized for M = %d", c->Mmax);
+  const size_t lds = narrow_lds_bytes(h, g, 1, L, 1);
+  if (lds > 160 * 1024) return fail(TNML_ERR_ARG, "merged tensor needs %zu B of LDS (> 160 KiB)", lds);
+  int rc = norm_envs_for_label_site(c);
+  if (rc) return rc;
+  std::vector<float> rel(bsize);
+  canon_to_rel(B_canon, rel.data(), left_dir, ml, mr, D, L);
+  HIP_TRY(hipMemcpyAsync(c->Bscr, rel.data(), bsize * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->red, 0, (size_t)c->slab_stride * sizeof(float), c->stream));
+  NarrowParams n{};
+  n.L = L; n.D = D; n.h = h; n.g = g; n.s = 1; n.m = 1; n.bsize = (int)bsize;
+  n.l2_flag = 1; n.lr = 0.f; n.wd = weight_dec;
+  n.red = c->red;
+  double *nbeh = left_dir ? c->Rn : c->Ln, *nahe = left_dir ? c->Ln : c->Rn;
+  const int bs_ = left_dir ? p + 2 : p - 1, as_ = left_dir ? p - 1 : p + 2;
+  n.Nh = (bs_ >= 0 && bs_ <= N - 1) ? c->norm_slot(nbeh, bs_) : nullptr;
+  n.Ng = (as_ >= 0 && as_ <= N - 1) ? c->norm_slot(nahe, as_) : nullptr;
+  n.Bnew = c->Bscr2;
+  n.dbg = c->dbg; n.status = c->status; n.counters = nullptr;
+  n.Bdirect = c->Bscr; n.stop_after_update = 1;
+  launch_narrow(n, lds, c->stream);
+  HIP_TRY(hipGetLastError());
+  c->last_bsize = (int)bsize; c->last_n = 1; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
+  const bool dbg_was = c->debug;
+  c->debug = true;
+  size_t nn = 0;
+  double sc[32];
+  rc = tnml_get_step_debug(c, TNML_DBG_L2_GRAD, grad_canon, capacity, &nn);
+  if (!rc) rc = tnml_get_step_debug(c, TNML_DBG_L2, sc, 32, &nn);
+  c->debug = dbg_was;
+  if (rc) return rc;
+  *loss = sc[0];
+  return TNML_OK;
+}
+
+extern "C" int tnml_svd_split(tnml_ctx *c, const float *mat, int rows, int cols, int m, float *US, float *SVh, double *sigma) {
+  // tensor_svd (Network_class.py:839-962) of an arbitrary rows x cols matrix: U sqrt(S) [rows][m], sqrt(S) Vh [m][cols]
+  if (!c || !mat || !US || !SVh) return fail(TNML_ERR_ARG, "NULL argument");
+  const int D = c->D;
+  if (rows < D || cols < D || rows % D || cols % D) return fail(TNML_ERR_ARG, "rows and cols must be multiples of D = %d", D);
+  const int h = rows / D, g = cols / D, nn = std::min(rows, cols);
+  if (m < 1 || m > nn) return fail(TNML_ERR_ARG, "kept rank %d outside [1, %d]", m, nn);
+  const size_t bsize = (size_t)rows * cols;
+  if (nn > 64) return fail(TNML_ERR_ARG, "min(rows, cols) = %d > 64: this build's in-LDS Jacobi handles n <= 64", nn);
+  if (bsize > c->bmax || (size_t)rows * m > c->bmax || (size_t)m * cols > c->bmax)
+    return fail(TNML_ERR_ARG, "matrix exceeds the buffers sized for M = %d", c->Mmax);
+  const size_t lds = narrow_lds_bytes(h, g, 1, 1, m);
+  if (lds > 160 * 1024) return fail(TNML_ERR_ARG, "matrix needs %zu B of LDS (> 160 KiB)", lds);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->Bscr, mat, bsize * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->red, 0, (size_t)c->slab_stride * sizeof(float), c->stream));
+  float *us_dev = c->slabs, *svh_dev = c->slabs + c->bmax;       // the slab area is idle outside a step
+  if ((size_t)c->nblk_cap * c->slab_stride < 2 * c->bmax) return fail(TNML_ERR_ARG, "slab scratch too small");
+  NarrowParams n{};
+  n.L = 1; n.D = D; n.h = h; n.g = g; n.s = 1; n.m = m; n.bsize = (int)bsize;
+  n.l2_flag = 0; n.lr = 0.f; n.wd = 0.f;
+  n.red = c->red;
+  n.Bnew = c->Bscr2;
+  n.out_behind = us_dev; n.ob_s_h = D * m; n.ob_s_d = m; n.ob_s_m = 1;
+  n.out_ahead = svh_dev; n.oa_s_m = cols; n.oa_s_d = g; n.oa_s_g = 1;
+  n.dbg = c->dbg; n.status = c->status; n.counters = c->counters;
+  n.Bdirect = c->Bscr;
+  launch_narrow(n, lds, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(US, us_dev, (size_t)rows * m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(SVh, svh_dev, (size_t)m * cols * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (sigma) {
+    std::vector<double> sg(64);
+    HIP_TRY(hipMemcpy(sg.data(), c->dbg + 4 * bsize, nn * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nn; ++i) sigma[i] = sg[i];
+  }
+  int st = 0;
+  HIP_TRY(hipMemcpy(&st, c->status, sizeof(int), hipMemcpyDeviceToHost));
+  if (st) {
+    HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
+    return fail(TNML_ERR_NONFINITE, st & 1 ? "non-finite values reached the SVD" : "Jacobi SVD did not converge");
   }
   return TNML_OK;
 }

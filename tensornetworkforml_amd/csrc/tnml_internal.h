@@ -82,6 +82,8 @@ struct NarrowParams {
   double *dbg;             // debug block (see narrow kernel), may be nullptr
   double *stamps;          // cycle stamps (diagnostic), may be nullptr
   unsigned long long *counters;  // [0] += jacobi sweeps, [1] += SVDs, [2] += jacobi rounds (always on)
+  const float *Bdirect;    // if set: the merged tensor (relative layout) is given, the two cores are not read
+  int stop_after_update;   // 1: return after B_new (standalone update_B / compute_L2_reg; needs dbg)
   int *status;             // device status word: bit0 non-finite, bit1 jacobi not converged
 };
 

@@ -43,3 +43,18 @@ def step_envs(d, pre):
         elif k.startswith(pre + 'Renv'):
             Renv[int(k[len(pre) + 4:])] = d[k]
     return Lenv, Renv
+
+
+def gauge_signs(B_dev, B_ref):
+    """Singular vectors are defined up to a sign, so the two outer bond indices (a, c) of a merged
+    tensor (a, d, d', c, l) carry independent +-1 factors between two correct implementations.
+    Returns (s_a, t_c) with B_dev ~ s_a t_c B_ref, read off the data."""
+    Mx = np.einsum('adecl,adecl->ac', B_dev, B_ref)
+    a0 = int(np.argmax(np.abs(Mx).sum(axis=1)))
+    t = np.where(Mx[a0] < 0, -1.0, 1.0)
+    s = np.where((Mx * t[None, :]).sum(axis=1) < 0, -1.0, 1.0)
+    return s, t
+
+
+def regauge(T, s, t):
+    return T * s[:, None, None, None, None] * t[None, None, None, :, None]

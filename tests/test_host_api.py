@@ -135,7 +135,7 @@ def test_mnist_reader_needs_local_files(tmp_path):
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, 'include', 'tnml.h')).read()
-    declared = set(re.findall(r'\b(tnml_[a-z0-9_]+)\s*\(', header))
+    declared = set(re.findall(r'\b(tnml_[A-Za-z0-9_]+)\s*\(', header))
     declared -= {'tnml_status'}
     lib = _hip.lib()
     missing = [s for s in declared if not hasattr(lib, s)]

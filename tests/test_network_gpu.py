@@ -198,3 +198,96 @@ def test_debug_var_hist_has_seven_series():
     ref_acc = [float(d['st%d_accuracy' % j]) for j in range(int(d['N']) - 1)]
     assert np.abs(np.array(vh[2]) - ref_acc).max() < 1e-6
     assert abs(vh[5][0] - float(d['st0_L2_loss'])) <= 1e-3 * abs(float(d['st0_L2_loss'])) + 1e-9
+
+
+def _named_to_canon(Tn, p):
+    """Merged Tensor on sites (p, p+1) -> (ml, D, D, mr, L) array, by axis name."""
+    names = [str(a) for a in Tn.axes_names]
+    want = ['left', 'd%d' % p, 'd%d' % (p + 1), 'right', 'l']
+    present = [n for n in want if n in names]
+    arr = np.transpose(Tn.elem, [names.index(n) for n in present])
+    return arr.reshape([arr.shape[present.index(n)] if n in present else 1 for n in want])
+
+
+@pytest.mark.parametrize('name', ['traj_fixed_softmax_full_cross_ent_L21', 'traj_reference_sigmoid_MSE_L21',
+                                  'traj_fixed_linear_MSE_L20', 'traj_fixed_L3'])
+def test_step_composed_of_update_B_L2_and_tensor_svd(name):
+    """The reference's sweep_step written out with the three methods it is made of
+    (contract -> update_B [-> compute_L2_reg] -> aggregate -> tensor_svd -> As, Network_class.py:484-566),
+    each checked against the oracle's record of the same step, for a right and then a left sweep."""
+    from custom_linalg_tools import contract
+    d = gu.load(name)
+    N, D, L, M = int(d['N']), int(d['D']), int(d['L']), int(d['M'])
+    policy, L2_flag = str(d['policy']), bool(d['L2_flag'])
+    lr, wd = float(d['lr']), float(d['wd'])
+    X, y = d['X'], d['y']
+    net = net_from_golden(d)
+    st = mo.MPSState(N, D, L, M, gu.indexed(d, 'init_core', N), 0)
+    y1h = mo.one_hot(y, L)
+    kw = dict(act_fn=str(d['act_fn']), loss_fn=str(d['loss_fn']), T=float(d['T']), trunc=policy)
+    for left_dir in (False, True):
+        ldf = int(left_dir)
+        f = net.forward(X)
+        f_o = mo.forward(st, X)
+        for k in range(N - 1):
+            l = net.l_pos
+            p = l - ldf
+            assert l == st.l_pos
+            rec = {}
+            st_before = st.copy()
+            st_before.Ln, st_before.Rn = {}, {}
+            f_o = mo.sweep_step(st, f_o, y1h, lr, wd, L2_flag=L2_flag, left_dir=left_dir, record=rec, **kw)
+            As = net.As
+            B = contract(As[l - ldf], As[l + 1 - ldf], 'right', 'left')
+            # singular vectors carry a sign gauge: the outer bonds of B differ by +-1 factors (s, t)
+            sg, tg = gu.gauge_signs(_named_to_canon(B, p), rec['B'])
+            assert relerr(_named_to_canon(B, p), gu.regauge(rec['B'], sg, tg)) < 2e-3
+            if L2_flag:
+                loss, grad = net.compute_L2_reg(B, wd, left_dir)
+                loss_o, grad_o = mo.compute_L2_reg(st_before, rec['B'], p, wd)
+                assert abs(loss - loss_o) < 2e-3 * abs(loss_o), (k, loss, loss_o)
+                assert list(grad.axes_names) == list(B.axes_names)
+                assert relerr(_named_to_canon(grad, p), gu.regauge(grad_o, sg, tg)) < 2e-3
+            vh = [[], []]
+            fT = Tensor(elem=np.asarray(f.elem), axes_names=['l', 'b'])
+            Bn = net.update_B(B, fT, y1h, lr, wd, L2_flag=L2_flag, ldf=ldf, var_hist=vh)
+            assert list(Bn.axes_names) == list(B.axes_names)
+            assert relerr(_named_to_canon(Bn, p), gu.regauge(rec['B_new'], sg, tg)) < 2e-3, (left_dir, k)
+            assert abs(vh[0][0] - rec['accuracy']) < 1e-6 and abs(vh[1][0] - rec['MAE']) < 2e-3
+            assert net.l_pos == l                                   # update_B moves nothing
+            # the SVD split, fed the way sweep_step feeds it (:528-560)
+            Bm = Tensor(elem=Bn.elem.copy(), axes_names=list(Bn.axes_names))
+            names = [str(a) for a in Bm.axes_names]
+            if not left_dir:
+                Bm.aggregate(axes_names=[n for n in ['d%d' % l, 'left'] if n in names], new_ax_name='i')
+                Bm.aggregate(axes_names=[n for n in ['d%d' % (l + 1), 'right', 'l'] if n in names], new_ax_name='j')
+            else:
+                Bm.aggregate(axes_names=[n for n in ['d%d' % (l - 1), 'left', 'l'] if n in names], new_ax_name='i')
+                Bm.aggregate(axes_names=[n for n in ['d%d' % l, 'right'] if n in names], new_ax_name='j')
+            Bm.transpose(['i', 'j'])
+            mat = Bm.elem.copy()
+            TU, TSVh = net.tensor_svd(Bm, left_dir)
+            m = rec['m']
+            # disaggregate puts the components of 'i' / 'j' first (Tensor_class.py:162-199)
+            assert [str(a) for a in TU.axes_names][-1] == 'right' and [str(a) for a in TSVh.axes_names][-1] == 'left'
+            assert TU.elem.shape[-1] == m and TSVh.elem.shape[-1] == m
+            US = TU.elem.reshape(-1, m)
+            SVh = TSVh.elem.reshape(-1, m).T
+            U, S, Vh = np.linalg.svd(mat, full_matrices=False)
+            best = (U[:, :m] * S[:m]) @ Vh[:m]
+            assert np.abs(US @ SVh - best).max() < 2e-3 * max(S[0], 1e-30), (left_dir, k)
+            # sqrt(S) on both factors: column norms of U sqrt(S) and row norms of sqrt(S) Vh are sqrt(sigma)
+            assert np.abs(np.linalg.norm(US, axis=0) ** 2 - S[:m]).max() < 2e-3 * S[0]
+            assert np.abs(np.linalg.norm(SVh, axis=1) ** 2 - S[:m]).max() < 2e-3 * S[0]
+            # carry on with the fused step so that both sides stay in lock-step
+            f = net.sweep_step(f, y1h, lr, len(y), wd, L2_flag=L2_flag, left_dir=left_dir)
+            assert relerr(f.elem, f_o) < 5e-3
+
+
+def test_tensor_svd_argument_errors_match_reference():
+    with quiet():
+        net = Network(N=6, M=4, L=2)
+    with pytest.raises(TypeError):
+        net.tensor_svd(np.zeros((4, 4)))
+    with pytest.raises(ValueError):
+        net.tensor_svd(Tensor(elem=np.zeros((2, 2, 2)), axes_names=['i', 'j', 'k']))
