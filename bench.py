@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--no-l2', action='store_true', help='weight decay as wd*B instead of the L2 norm term')
     ap.add_argument('--cpu-steps', type=int, default=40, help='oracle steps timed for cpu_baseline (0 = skip)')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--svd-stop', type=float, default=None, help='Jacobi stopping threshold (tnml_set_svd_stop); default: the library default')
     ap.add_argument('--no-cold', action='store_true', help='skip the re-initialised (cold start) passes')
     args = ap.parse_args()
 
@@ -109,6 +110,8 @@ def main():
     if _hip.device_count() <= local_rank:
         raise SystemExit('bench.py needs a gfx950 GPU per rank (visible: %d)' % _hip.device_count())
     ctx = _hip.Context(N, D, L, M, b, device=local_rank)
+    if args.svd_stop is not None:
+        ctx.set_svd_stop(args.svd_stop)
     tdist.attach_comm(ctx, rank, world)
 
     X, y = synth(N, b, L, 1234 + rank)          # every rank owns a different shard
@@ -180,7 +183,8 @@ def main():
         'finite': finite,
         'final_accuracy': float(met[-1, 0]),
         # the SVD is iterative: how much work the timed passes actually contained
-        'jacobi': {'sweeps_per_svd': sw_tot / max(n_svd, 1), 'rounds_per_svd': rounds_tot / max(n_svd, 1)},
+        'jacobi': {'sweeps_per_svd': sw_tot / max(n_svd, 1), 'rounds_per_svd': rounds_tot / max(n_svd, 1),
+                   'svd_stop2': args.svd_stop if args.svd_stop is not None else 1e-6},
     }
 
     if rank == 0 and not args.no_kernel_profile:

@@ -142,6 +142,13 @@ int tnml_l2_term(tnml_ctx *ctx, const float *B_canon, int left_dir, float weight
 int tnml_svd_split(tnml_ctx *ctx, const float *mat, int rows, int cols, int m, float *US, float *SVh,
                    double *sigma);
 
+/* Accuracy / speed of the in-kernel Jacobi SVD (no reference analogue: the reference calls LAPACK,
+ * Network_class.py:887).  The iteration ends after a sweep in which every rotation had
+ * g^2 <= stop2 * scale^2; the off-diagonals left behind are of relative size ~stop2.  Default 1e-6
+ * (truncated product within ~6e-6 max|B| of LAPACK's); 1e-4 saves about one sweep in five and leaves ~2e-4;
+ * 1e-8 costs one more and reaches ~1e-6.  Allowed range [1e-12, 1e-2]. */
+int tnml_set_svd_stop(tnml_ctx *ctx, double stop2);
+
 /* Network.apply_act_func / compute_loss_derivate on the device-resident f (:767-835);
  * act_out, lossder_out [L][b], either may be NULL.  input_is_activated != 0: f already went
  * through the activation (what compute_loss_derivate receives, :800), only the derivative runs. */

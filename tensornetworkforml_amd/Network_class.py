@@ -127,13 +127,14 @@ class Network():
     """
 
     def __init__(self, N, M, D=2, L=10, T=0.1, normalize=False, calibration_X=None, act_fn='linear',
-                 loss_fn='cross_entropy', check=False, trunc='reference', device=0):
+                 loss_fn='cross_entropy', check=False, trunc='reference', device=0, svd_stop=None):
         self.N, self.D, self.L, self.M, self.T = N, D, L, M, T
         assert act_fn in _ACTS, "Please select an activation function between 'linear', 'sigmoid', 'softmax'"
         assert loss_fn in _LOSSES, "Please select a loss function between 'MSE', 'cross_entropy', 'full_cross_ent'"
         assert trunc in _hip.TRUNC, "trunc must be 'reference' or 'fixed'"
         self.act_fn, self.loss_fn, self.trunc = act_fn, loss_fn, trunc
         self._device = device
+        self._svd_stop = svd_stop          # None: the library default (include/tnml.h, tnml_set_svd_stop)
         self._init_runtime()
         self._l_pos = 0
 
@@ -195,6 +196,8 @@ class Network():
     def _context(self, b):
         if self._ctx is None:
             self._ctx = _hip.Context(self.N, self.D, self.L, self.M, max(int(b), 1), self._device)
+            if getattr(self, '_svd_stop', None) is not None:
+                self._ctx.set_svd_stop(self._svd_stop)
         return self._ctx
 
     def _collect_user_edits(self):

@@ -34,7 +34,13 @@ namespace tnml {
 // be separated from the kept subspace).  Emulated on headline-shaped matrices: 7.5 sweeps instead
 // of 9.4, truncated product within 2e-8 of LAPACK's (tools/jacobi_emulation.py).
 constexpr double kJacobiTol2 = 1e-14;     // below: pair left alone
-constexpr double kJacobiBig2 = 1e-4;      // above: "big" rotation; a sweep without one ends the iteration
+// "big" rotation: g^2 / scale2 above NarrowParams::svd_stop2 (default kJacobiStop2).  A sweep without one ends
+// the iteration: quadratic convergence then leaves off-diagonals of relative size ~svd_stop2.  Measured on
+// the merged tensors of a C3-shaped run (tools/jacobi_correction_emulation.py, probe_svd_accuracy.py):
+//   svd_stop2   sweeps (n = 40)   worst |A.C - best rank-m| / max|B|   worst relative error of a kept sigma
+//   1e-4        3.9               2e-4                                  5e-6
+//   1e-6        5.0               6e-6                                  7e-11
+//   1e-8        5.9               1e-6                                  8e-12
 constexpr double kKeptFrac = 0.2;
 constexpr double kJacobiAbs = 1e-15;      // |g| / trace floor: eigenvalues under 1e-15 trace are float32 noise of B
 
@@ -43,7 +49,7 @@ constexpr double kJacobiAbs = 1e-15;      // |g| / trace floor: eigenvalues unde
 // t = 2g / (d + sign(d) sqrt(d^2 + 4 g^2)) can neither overflow nor (above the floor) underflow;
 // c is refined to float64 by one Newton step on rsqrt so that c^2 + s^2 = 1 to ~1e-14.
 struct Rot { double c, s, t; int level; };
-__device__ inline Rot jacobi_rot(double a, double b, double g, double kept2, double abs2) {
+__device__ inline Rot jacobi_rot(double a, double b, double g, double kept2, double abs2, double big2) {
   Rot r; r.c = 1.0; r.s = 0.0; r.t = 0.0; r.level = 0;
   const double g2 = g * g;
   const double sc = fmax(fabs(a * b), kept2);
@@ -55,8 +61,16 @@ __device__ inline Rot jacobi_rot(double a, double b, double g, double kept2, dou
   const double x = fma(td, td, 1.0);                           // in [1, 2]
   double c0 = (double)__builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
   c0 = c0 * fma(-0.5 * x, c0 * c0, 1.5);
-  if (act) { r.c = c0; r.s = c0 * td; r.t = td; r.level = (g2 > kJacobiBig2 * sc) ? 2 : 1; }
+  if (act) { r.c = c0; r.s = c0 * td; r.t = td; r.level = (g2 > big2 * sc) ? 2 : 1; }
   return r;
+}
+
+// one-lane wave shift of a double: CTRL 0x138 = wave_shr:1 (lane i receives lane i-1), 0x130 = wave_shl:1
+template <int CTRL> __device__ inline double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
 
 // block-wide sum of up to 3 doubles; result valid in every thread.  scratch: >= 3*16 doubles.
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   TNML_STAMP(3);
   // ---- phase 6: Gram matrix in float64 (padded to ne x ne with a zero row/column), V = I ----------
   //   W(x, kk) = short_rows ? Bm[kk][x] : Bm[x][kk]   with Bm = B_new as (r x c) row-major
-  double *G0 = k.Z, *G1 = k.Z + ne * ne, *V0 = k.Z + 2 * ne * ne, *V1 = k.Z + 3 * ne * ne;
+  double *G0 = k.Z, *G1 = k.Z + ne * ne, *V0 = k.Z + 2 * ne * ne;
   for (int e = tid; e < ne * ne; e += NT) {           // zero fill (covers the padding) and V = I
     G0[e] = 0.0;
     V0[e] = (e / ne == e % ne) ? 1.0 : 0.0;
@@ -351,41 +365,52 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   // (piInv(2k), piInv(2k+1)) in today's positions, its new diagonal follows from today's diagonal
   // blocks (alpha' = alpha - t gamma, beta' = beta + t gamma) and its new off-diagonal element from
   // one element of the updated block (A, B), which the thread recomputes itself.
-  constexpr int T0 = 64;
+  // Thread roles.  wave 0: parameter threads (tid < np).  waves 1..NVW: V.  The rest: G items.
+  //   V never touches LDS during the iteration: a thread keeps kVR 2x2 blocks (row pairs P0..P0+kVR-1,
+  //   column pair Q = its lane within a group of np lanes) in registers; the column rotation is local and
+  //   the tournament move (top element of pair Q -> pair Q+1, bottom element -> pair Q-1) is a one-lane
+  //   wave shift (DPP wave_shr / wave_shl, tools/ubench/dpp_wave_shift.hip).
+  constexpr int kVR = 2;
+  const int gpw = 64 / np;                               // groups of np lanes per V wave (np <= 32)
+  const int NVW = (np + kVR * gpw - 1) / (kVR * gpw);    // V waves
+  const int T0 = 64 * (1 + NVW);
   const int NW = NT - T0;
+  const int vlane = tid & 63, vgrp = vlane / np, vQ = vlane - vgrp * np;
+  const bool isVwave = tid >= 64 && tid < T0;
+  const int vP0 = (((tid >> 6) - 1) * gpw + vgrp) * kVR;
+  const bool vLaneOk = isVwave && vgrp < gpw;
+  double vb[kVR][4];                                     // {v11, v12, v21, v22} per block
+#pragma unroll
+  for (int r = 0; r < kVR; ++r) {
+    const double one = (vP0 + r == vQ) ? 1.0 : 0.0;      // V = I
+    vb[r][0] = one; vb[r][1] = 0.0; vb[r][2] = 0.0; vb[r][3] = one;
+  }
   int sweeps = 0, converged = 0;
-  double *Gc = G0, *Gn = G1, *Vc = V0, *Vn = V1;
-  // items: the np(np+1)/2 blocks P <= Q of the symmetric G (only entries with row <= column are kept
-  // up to date), then the np*np blocks of V; at most 2 per worker thread (n <= 64)
+  double *Gc = G0, *Gn = G1;
+  // G items: the np(np+1)/2 blocks P <= Q of the symmetric G (only entries with row <= column are kept
+  // up to date); at most 2 per worker thread (np <= 32: 528 items on >= 448 threads)
   constexpr int MAXI = 2;
   const int nG = np * (np + 1) / 2;
-  bool itValid[MAXI], itV[MAXI], itDiag[MAXI];
+  bool itValid[MAXI], itDiag[MAXI];
   int itSrc[MAXI], itCsQ[MAXI], itCsP[MAXI], itD11[MAXI], itD12[MAXI], itD21[MAXI], itD22[MAXI];
 #pragma unroll
   for (int u = 0; u < MAXI; ++u) {
     const int it = (tid - T0) + u * NW;
-    itValid[u] = tid >= T0 && it < nG + np * np;
-    itV[u] = it >= nG;
+    itValid[u] = tid >= T0 && it < nG;
     int P = 0, Q = 0;
-    if (itValid[u]) {
-      if (itV[u]) { P = (it - nG) / np; Q = (it - nG) - P * np; }
-      else {                                  // it-th pair (P <= Q) in row-major order of the upper triangle
-        int rem = it;
-        while (rem >= np - P) { rem -= np - P; ++P; }
-        Q = P + rem;
-      }
+    if (itValid[u]) {                         // it-th pair (P <= Q) in row-major order of the upper triangle
+      int rem = it;
+      while (rem >= np - P) { rem -= np - P; ++P; }
+      Q = P + rem;
     }
     const int c1 = k.sPi[2 * Q], c2 = k.sPi[2 * Q + 1];
-    const int o1 = itV[u] ? 2 * P : k.sPi[2 * P], o2 = itV[u] ? 2 * P + 1 : k.sPi[2 * P + 1];
+    const int o1 = k.sPi[2 * P], o2 = k.sPi[2 * P + 1];
     itSrc[u] = (2 * P) * ne + 2 * Q;
     itCsQ[u] = 4 * Q; itCsP[u] = 4 * P;
-    itDiag[u] = (!itV[u]) && P == Q;
-    if (itV[u]) {
-      itD11[u] = o1 * ne + c1; itD12[u] = o1 * ne + c2; itD21[u] = o2 * ne + c1; itD22[u] = o2 * ne + c2;
-    } else {                                  // G: every element lands at (min, max) of its new position
-      itD11[u] = min(o1, c1) * ne + max(o1, c1); itD12[u] = min(o1, c2) * ne + max(o1, c2);
-      itD21[u] = min(o2, c1) * ne + max(o2, c1); itD22[u] = min(o2, c2) * ne + max(o2, c2);
-    }
+    itDiag[u] = P == Q;
+    // every element lands at (min, max) of its new position
+    itD11[u] = min(o1, c1) * ne + max(o1, c1); itD12[u] = min(o1, c2) * ne + max(o1, c2);
+    itD21[u] = min(o2, c1) * ne + max(o2, c1); itD22[u] = min(o2, c2) * ne + max(o2, c2);
   }
   const double abs2 = kJacobiAbs * kJacobiAbs;      // trace is ~1 after scaling
   // parameter-thread constants
@@ -408,26 +433,14 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   };
 
   int cur = 0;
-  if (p.stamps && tid == 0) t_c1 = __builtin_amdgcn_s_memtime();
-  if (n > 1) {
-    double kept2 = kept_scale(Gc);
-    if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
-    if (isParam) {                                   // rotations of the very first round
-      const double2 top = *reinterpret_cast<const double2 *>(Gc + (2 * tid) * ne + 2 * tid);
-      const Rot r = jacobi_rot(top.x, Gc[(2 * tid + 1) * ne + 2 * tid + 1], top.y, kept2, abs2);
-      double *o = k.dCS + (cur * np + tid) * 4;
-      o[0] = r.c; o[1] = r.s; o[2] = r.t;
-      if (r.level >= 1) k.sFlag[0] = 1;
-      if (r.level >= 2) k.sFlag[1] = 1;
-    }
-    __syncthreads();
-    for (; sweeps < kJacobiMaxSweeps; ++sweeps) {
-      for (int rnd = 0; rnd < ne - 1; ++rnd) {
+  double kept2 = 0.0;
+  // one round; xP / xG / xV switch the parameter threads, the G items and the V items (all true except in
+  // the timing experiment at the end of the kernel)
+  auto jacobi_round = [&](const bool stampRound, const bool xP, const bool xG, const bool xV) {
         const double *csc = k.dCS + cur * np * 4;
-        const bool stampRound = p.stamps && tid == 0 && sweeps == 0 && rnd == 7;
         unsigned long long r_t0 = 0, r_t1 = 0, r_t2 = 0, r_t3 = 0;
         if (stampRound) r_t0 = __builtin_amdgcn_s_memtime();
-        if (isParam) {
+        if (isParam && xP) {
           const double2 csA = *reinterpret_cast<const double2 *>(csc + 4 * pA);
           const double2 csB = *reinterpret_cast<const double2 *>(csc + 4 * pB);
           const double tA = csc[4 * pA + 2], tB = csc[4 * pB + 2];
@@ -454,45 +467,51 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
           const double h0 = ra ? fma(csA.y, r0.x, csA.x * r1.x) : fma(csA.x, r0.x, -csA.y * r1.x);
           const double h1 = ra ? fma(csA.y, r0.y, csA.x * r1.y) : fma(csA.x, r0.y, -csA.y * r1.y);
           const double ng = rb ? fma(csB.y, h0, csB.x * h1) : fma(csB.x, h0, -csB.y * h1);
-#ifdef TNML_EXP_NO_PARAM
-          Rot r; r.c = 0.8; r.s = 0.6; r.t = 0.75; r.level = 2; r.c += 1e-300 * (na + nb + ng);
-#else
           if (stampRound) { asm volatile("" :: "v"(na), "v"(nb), "v"(ng)); r_t1 = __builtin_amdgcn_s_memtime(); }
-          const Rot r = jacobi_rot(na, nb, ng, kept2, abs2);
+          const Rot r = jacobi_rot(na, nb, ng, kept2, abs2, p.svd_stop2);
           if (stampRound) { asm volatile("" :: "v"(r.c), "v"(r.s)); r_t2 = __builtin_amdgcn_s_memtime(); }
-#endif
           double *o = k.dCS + ((cur ^ 1) * np + tid) * 4;
           o[0] = r.c; o[1] = r.s; o[2] = r.t;
           if (r.level >= 1) k.sFlag[0] = 1;
           if (r.level >= 2) k.sFlag[1] = 1;
         }
+        if (isVwave && xV) {                                    // whole waves: every lane runs the shifts
+          const double2 cs = *reinterpret_cast<const double2 *>(csc + 4 * (vLaneOk ? vQ : 0));
+#pragma unroll
+          for (int r = 0; r < kVR; ++r) {
+            const double n11 = cs.x * vb[r][0] - cs.y * vb[r][1], n12 = cs.y * vb[r][0] + cs.x * vb[r][1];
+            const double n21 = cs.x * vb[r][2] - cs.y * vb[r][3], n22 = cs.y * vb[r][2] + cs.x * vb[r][3];
+            if (np > 1) {
+              const double t1 = dpp_f64<0x138>(n11), t2 = dpp_f64<0x138>(n21);      // top column of pair Q-1
+              const double b1 = dpp_f64<0x138>(n12), b2 = dpp_f64<0x138>(n22);      // bottom column of pair Q-1
+              const double c1 = dpp_f64<0x130>(n12), c2 = dpp_f64<0x130>(n22);      // bottom column of pair Q+1
+              vb[r][0] = vQ == 0 ? n11 : (vQ == 1 ? b1 : t1);
+              vb[r][2] = vQ == 0 ? n21 : (vQ == 1 ? b2 : t2);
+              vb[r][1] = vQ == np - 1 ? n11 : c1;
+              vb[r][3] = vQ == np - 1 ? n21 : c2;
+            } else {
+              vb[r][0] = n11; vb[r][1] = n12; vb[r][2] = n21; vb[r][3] = n22;
+            }
+          }
+        }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-          if (!itValid[u]) continue;
-#ifdef TNML_EXP_NO_V
-          if (itV[u]) continue;
-#endif
-#ifdef TNML_EXP_NO_G
-          if (!itV[u]) continue;
-#endif
+          if (!itValid[u] || !xG) continue;
           const double2 csq = *reinterpret_cast<const double2 *>(csc + itCsQ[u]);
-          const double *src = (itV[u] ? Vc : Gc) + itSrc[u];
-          double *dst = itV[u] ? Vn : Gn;
+          const double2 csp = *reinterpret_cast<const double2 *>(csc + itCsP[u]);
+          const double *src = Gc + itSrc[u];
           const double2 r0 = *reinterpret_cast<const double2 *>(src);
           double2 r1 = *reinterpret_cast<const double2 *>(src + ne);
           if (itDiag[u]) r1.x = r0.y;                           // lower element of a diagonal block = its mirror
-          double h11 = r0.x, h12 = r0.y, h21 = r1.x, h22 = r1.y;
-          if (!itV[u]) {                                        // rows by R_P^T (G only; V keeps its rows)
-            const double2 csp = *reinterpret_cast<const double2 *>(csc + itCsP[u]);
-            h11 = csp.x * r0.x - csp.y * r1.x; h12 = csp.x * r0.y - csp.y * r1.y;
-            h21 = csp.y * r0.x + csp.x * r1.x; h22 = csp.y * r0.y + csp.x * r1.y;
-          }
+          // rows by R_P^T, columns by R_Q
+          const double h11 = csp.x * r0.x - csp.y * r1.x, h12 = csp.x * r0.y - csp.y * r1.y;
+          const double h21 = csp.y * r0.x + csp.x * r1.x, h22 = csp.y * r0.y + csp.x * r1.y;
           double n11 = csq.x * h11 - csq.y * h12, n12 = csq.y * h11 + csq.x * h12;
           double n21 = csq.x * h21 - csq.y * h22, n22 = csq.y * h21 + csq.x * h22;
           if (itDiag[u] && csq.y != 0.0) { n12 = 0.0; n21 = 0.0; }   // the annihilated element, exactly
-          dst[itD11[u]] = n11; dst[itD12[u]] = n12;
-          if (!itDiag[u]) dst[itD21[u]] = n21;                  // (n21 of a diagonal block is n12's mirror)
-          dst[itD22[u]] = n22;
+          Gn[itD11[u]] = n11; Gn[itD12[u]] = n12;
+          if (!itDiag[u]) Gn[itD21[u]] = n21;                   // (n21 of a diagonal block is n12's mirror)
+          Gn[itD22[u]] = n22;
         }
         __syncthreads();
         if (stampRound) {
@@ -500,9 +519,27 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
           p.stamps[14] = (double)(r_t1 - r_t0); p.stamps[15] = (double)(r_t2 - r_t1); p.stamps[16] = (double)(r_t3 - r_t2);
         }
         double *tsw = Gc; Gc = Gn; Gn = tsw;
-        tsw = Vc; Vc = Vn; Vn = tsw;
         cur ^= 1;
-      }
+  };
+  if (p.stamps && tid == 0) t_c1 = __builtin_amdgcn_s_memtime();
+#ifdef TNML_EXP_PRIO
+  if (tid < 64) __builtin_amdgcn_s_setprio(3);
+#endif
+  if (n > 1) {
+    kept2 = kept_scale(Gc);
+    if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
+    if (isParam) {                                   // rotations of the very first round
+      const double2 top = *reinterpret_cast<const double2 *>(Gc + (2 * tid) * ne + 2 * tid);
+      const Rot r = jacobi_rot(top.x, Gc[(2 * tid + 1) * ne + 2 * tid + 1], top.y, kept2, abs2, p.svd_stop2);
+      double *o = k.dCS + (cur * np + tid) * 4;
+      o[0] = r.c; o[1] = r.s; o[2] = r.t;
+      if (r.level >= 1) k.sFlag[0] = 1;
+      if (r.level >= 2) k.sFlag[1] = 1;
+    }
+    __syncthreads();
+    for (; sweeps < kJacobiMaxSweeps; ++sweeps) {
+      for (int rnd = 0; rnd < ne - 1; ++rnd)
+        jacobi_round(p.stamps && tid == 0 && sweeps == 0 && rnd == 7, true, true, true);
       // the flags cover the rotations applied in the last ne-2 rounds plus the one prepared for the
       // next round: any ne-1 consecutive rounds form a complete sweep
       const int any_rot = k.sFlag[0], big_rot = k.sFlag[1];
@@ -518,7 +555,18 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   } else {
     converged = 1;
   }
-  double *V = Vc;
+  // the eigenvectors leave the registers: V[row][column position], as phase 9 reads them
+  double *V = V0;
+  if (vLaneOk) {
+#pragma unroll
+    for (int r = 0; r < kVR; ++r) {
+      const int P = vP0 + r;
+      if (P < np) {
+        *reinterpret_cast<double2 *>(V + (2 * P) * ne + 2 * vQ) = make_double2(vb[r][0], vb[r][1]);
+        *reinterpret_cast<double2 *>(V + (2 * P + 1) * ne + 2 * vQ) = make_double2(vb[r][2], vb[r][3]);
+      }
+    }
+  }
   if (p.stamps && tid == 0) t_c2 = __builtin_amdgcn_s_memtime();
 
   // ---- phase 8: eigenvalues = diag(G), descending order -------------------------------------------
@@ -633,6 +681,22 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     p.metrics[1] = (float)((double)p.red[Bs + 1] * inv / (double)L);
     if (p.red[Bs + 2] != 0.f) atomicOr(p.status, 1);
   }
+#ifdef TNML_EXP_ROUND_TIMING
+  // timing experiment (tools/build_exp.sh): ne-1 rounds each with parts of the round switched off, on the
+  // dead Jacobi buffers; cycles per round land in stamps[24..27]
+  if (p.stamps && n > 2) {
+    __syncthreads();
+    for (int variant = 0; variant < 4; ++variant) {
+      const bool xP = variant != 3, xG = variant == 0 || variant == 2 || variant == 3, xV = variant == 0 || variant == 1 || variant == 3;
+      __syncthreads();
+      const unsigned long long e0 = __builtin_amdgcn_s_memtime();
+      for (int rnd = 0; rnd < ne - 1; ++rnd) jacobi_round(false, xP, xG, xV);
+      const unsigned long long e1 = __builtin_amdgcn_s_memtime();
+      if (tid == 0) p.stamps[24 + variant] = (double)(e1 - e0) / (double)(ne - 1);
+    }
+    if (vLaneOk) for (int r = 0; r < kVR; ++r) for (int q = 0; q < 4; ++q) V0[(vP0 + r) * 4 + q] += vb[r][q];   // keep V alive
+  }
+#endif
 }
 
 void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st) {

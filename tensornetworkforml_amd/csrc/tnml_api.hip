@@ -60,6 +60,7 @@ struct tnml_ctx {
   int prev_left_dir = 0, prev_p = -1;
   int last_bsize = 0, last_n = 0, last_h = 0, last_g = 0, last_left_dir = 0;
   bool debug = false, profile = false, stamps = false;
+  double svd_stop2 = kSvdStop2Default;
   double prof_ms[4] = {0, 0, 0, 0};
   long long prof_n[4] = {0, 0, 0, 0};
   // device buffers
@@ -186,7 +187,7 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   c->metrics_cap = N;
   HIP_TRY(hipMalloc(&c->metrics, (size_t)c->metrics_cap * 2 * sizeof(float)));
   HIP_TRY(hipMalloc(&c->scal, 64 * sizeof(float)));
-  c->dbg_elems = 4 * c->bmax + 64 + 32;   // 4 tensors, sigma[64], 5 scalars, 9 stamps
+  c->dbg_elems = 4 * c->bmax + 64 + 48;   // 4 tensors, sigma[64], 5 scalars, stamps
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
   HIP_TRY(hipMalloc(&c->status, sizeof(int)));
   HIP_TRY(hipMemsetAsync(c->status, 0, sizeof(int), c->stream));
@@ -732,6 +733,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     n.metrics = c->metrics + 2 * (size_t)step;
     n.dbg = (c->debug || mode == 1) ? c->dbg : nullptr;
     n.Bdirect = Bdirect_dev;
+    n.svd_stop2 = c->svd_stop2;
     n.stop_after_update = mode == 1;
     if (mode == 1) { n.Bnew = c->Bscr2; n.Nh_new = nullptr; }
     n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + 64 + 5 : nullptr;
@@ -888,15 +890,16 @@ extern "C" int tnml_l2_term(tnml_ctx *c, const float *B_canon, int left_dir, flo
   n.Bnew = c->Bscr2;
   n.dbg = c->dbg; n.status = c->status; n.counters = nullptr;
   n.Bdirect = c->Bscr; n.stop_after_update = 1;
+  n.svd_stop2 = c->svd_stop2;
   launch_narrow(n, lds, c->stream);
   HIP_TRY(hipGetLastError());
   c->last_bsize = (int)bsize; c->last_n = 1; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
   const bool dbg_was = c->debug;
   c->debug = true;
   size_t nn = 0;
-  double sc[32];
+  double sc[48];
   rc = tnml_get_step_debug(c, TNML_DBG_L2_GRAD, grad_canon, capacity, &nn);
-  if (!rc) rc = tnml_get_step_debug(c, TNML_DBG_L2, sc, 32, &nn);
+  if (!rc) rc = tnml_get_step_debug(c, TNML_DBG_L2, sc, 48, &nn);
   c->debug = dbg_was;
   if (rc) return rc;
   *loss = sc[0];
@@ -930,6 +933,7 @@ extern "C" int tnml_svd_split(tnml_ctx *c, const float *mat, int rows, int cols,
   n.out_ahead = svh_dev; n.oa_s_m = cols; n.oa_s_d = g; n.oa_s_g = 1;
   n.dbg = c->dbg; n.status = c->status; n.counters = c->counters;
   n.Bdirect = c->Bscr;
+  n.svd_stop2 = c->svd_stop2;
   launch_narrow(n, lds, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(US, us_dev, (size_t)rows * m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -971,6 +975,13 @@ extern "C" int tnml_get_env(tnml_ctx *c, int side, int site, float *out, size_t 
   return TNML_OK;
 }
 
+extern "C" int tnml_set_svd_stop(tnml_ctx *c, double stop2) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  if (!(stop2 >= 1e-12 && stop2 <= 1e-2)) return fail(TNML_ERR_ARG, "svd stop threshold %g outside [1e-12, 1e-2]", stop2);
+  c->svd_stop2 = stop2;
+  return TNML_OK;
+}
+
 extern "C" int tnml_debug_enable(tnml_ctx *c, int on) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   c->debug = (on & 1) != 0;    // 1: full capture of every step
@@ -984,9 +995,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
   if (c->last_bsize <= 0) return fail(TNML_ERR_STATE, "no step has run yet");
   HIP_TRY(hipSetDevice(c->device));
   const size_t Bs = c->last_bsize;
-  std::vector<double> hbuf(4 * Bs + 64 + 32);   // tensors, sigma, 5 scalars, 14 stamps
+  std::vector<double> hbuf(4 * Bs + 64 + 48);   // tensors, sigma, 5 scalars, 14 stamps
   HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, (4 * Bs + 64 + 5) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + 64 + 5, c->dbg + 4 * c->bmax + 64 + 5, 24 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + 64 + 5, c->dbg + 4 * c->bmax + 64 + 5, 35 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   auto tensor_out = [&](size_t block) -> int {
     if (capacity < Bs) return fail(TNML_ERR_ARG, "capacity too small");
@@ -1014,9 +1025,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
       if (n_out) *n_out = c->last_n;
       return TNML_OK;
     case TNML_DBG_L2:
-      if (capacity < 29) return fail(TNML_ERR_ARG, "capacity too small");
-      memcpy(out, hbuf.data() + 4 * Bs + 64, 29 * sizeof(double));
-      if (n_out) *n_out = 29;
+      if (capacity < 40) return fail(TNML_ERR_ARG, "capacity too small");
+      memcpy(out, hbuf.data() + 4 * Bs + 64, 40 * sizeof(double));
+      if (n_out) *n_out = 40;
       return TNML_OK;
   }
   return fail(TNML_ERR_ARG, "unknown debug selector %d", what);

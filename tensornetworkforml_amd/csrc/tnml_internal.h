@@ -14,7 +14,8 @@ constexpr int kD = 2;           // feature dimension the kernels are specialised
 constexpr int kTS = 32;         // samples per workgroup in the wide step kernel (v1)
 constexpr int kWideThreads = 1024; // 4 waves per SIMD: the v1 formulation is latency-bound
 constexpr int kNarrowThreads = 1024;
-constexpr int kMetricSlots = 4; // per-slab tail: correct count, sum|y-fa|, non-finite count, pad
+constexpr int kMetricSlots = 4;
+constexpr double kSvdStop2Default = 1e-6;   // see jacobi_rot (kernels_narrow.hip) and tnml_set_svd_stop // per-slab tail: correct count, sum|y-fa|, non-finite count, pad
 
 // A plain (label-free) core or the label core addressed in the sweep-relative frame.
 //   plain:  A(in, d, out)      = base[in*s_in + d*s_d + out*s_out]
@@ -84,6 +85,7 @@ struct NarrowParams {
   unsigned long long *counters;  // [0] += jacobi sweeps, [1] += SVDs, [2] += jacobi rounds (always on)
   const float *Bdirect;    // if set: the merged tensor (relative layout) is given, the two cores are not read
   int stop_after_update;   // 1: return after B_new (standalone update_B / compute_L2_reg; needs dbg)
+  double svd_stop2;        // Jacobi stops after a sweep whose rotations all had g^2 / scale^2 <= svd_stop2 (tnml_set_svd_stop)
   int *status;             // device status word: bit0 non-finite, bit1 jacobi not converged
 };
 

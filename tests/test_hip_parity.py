@@ -237,3 +237,56 @@ def test_rccl_path_single_rank(monkeypatch):
         ctx.close()
     for a, b in zip(outs[0], outs[1]):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.parametrize('stop2,tol', [(None, 2e-5), (1e-4, 1e-3), (1e-8, 5e-6)])
+def test_svd_accuracy_late_in_training(stop2, tol):
+    """The Jacobi iteration stops early once its rotations are small (tnml_set_svd_stop); late in training
+    that happens after few sweeps.  Every step of the 7th and 8th pass: the product of the two new cores
+    against LAPACK's best rank-m approximation of the device's own updated merged tensor, and the kept
+    singular values."""
+    N, M, b, L, D = 20, 12, 600, 2, 2
+    rng = np.random.default_rng(3)
+    p = rng.random((b, N)) * (rng.random((b, N)) > 0.81)
+    X = np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32)
+    y = rng.integers(0, L, b)
+    st = mo.MPSState(N, D, L, M, mo.random_cores(N, M, D, L, rng=rng, scale=M * 0.5 * 0.64 * D))
+    mo.calibrate(st, X.astype(np.float64))
+    ctx = make_ctx(N, D, L, M, [c.astype(np.float32) for c in st.cores], 0, X, y)
+    if stop2 is not None:
+        ctx.set_svd_stop(stop2)
+    hp = (1e-3, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
+
+    def matricize(B, left):
+        ml, _, _, mr, _ = B.shape
+        return B.reshape(ml * D, D * mr * L) if not left else np.transpose(B, (0, 1, 4, 2, 3)).reshape(ml * D * L, D * mr)
+
+    worst_prod = worst_sig = 0.0
+    for ps in range(8):
+        ctx.forward(want_f=False)
+        left = ctx.l_pos == N - 1
+        if ps < 6:
+            ctx.sweep(left, N - 1, True, *hp, want_metrics=False, want_f=False)
+            continue
+        ctx.debug_enable(True)
+        for k in range(N - 1):
+            _, bond0, lp0 = ctx.get_cores()
+            ctx.sweep(left, 1, k == 0, *hp)
+            pp = lp0 - 1 if left else lp0
+            ml = 1 if pp == 0 else int(bond0[pp - 1])
+            mr = 1 if pp == N - 2 else int(bond0[pp + 1])
+            Bm = matricize(ctx.step_debug('B_new').reshape(ml, D, D, mr, L), left)
+            sig = ctx.step_debug('sigma')
+            cores1, bond1, _ = ctx.get_cores()
+            m = int(bond1[pp])
+            A, C = cores1[pp].astype(np.float64), cores1[pp + 1].astype(np.float64)
+            prod = np.einsum('adkl,kec->adecl', A, C) if A.ndim == 4 else np.einsum('adk,kecl->adecl', A, C)
+            U, S, Vh = np.linalg.svd(Bm, full_matrices=False)
+            best = (U[:, :m] * S[:m]) @ Vh[:m]
+            worst_prod = max(worst_prod, np.abs(matricize(prod, left) - best).max() / np.abs(Bm).max())
+            worst_sig = max(worst_sig, (np.abs(sig[:m] - S[:m]) / S[0]).max())
+        ctx.debug_enable(False)
+    print('svd_stop2', stop2, 'worst product error %.2e, worst kept sigma error %.2e' % (worst_prod, worst_sig))
+    assert worst_prod < tol
+    assert worst_sig < tol
+    ctx.close()

@@ -37,6 +37,8 @@ def stamp_line(tag, sc):
         print('   one round, parameter wave: loads+new elements %d / rotation %d / stores+barrier %d cycles' % tuple(sc[19:22]))
     if len(sc) > 28:
         print('   wide kernel WG0: x-stage %d / operand stage %d / f+env MFMA %d / activation %d / gP %d / dB MFMA+store %d cycles (own activation %d)' % tuple(sc[22:29]))
+    if len(sc) > 32 and sc[29] > 0:
+        print('   round-timing experiment (cycles per round): full %d / no G items %d / no V items %d / workers only %d' % tuple(sc[29:33]))
     if len(sc) > 13:
         print('   post split: sort %d / cores %d / norm env + metrics %d cycles' % (sc[11], sc[12], sc[13]))
 
@@ -73,6 +75,16 @@ for _ in range(4):
 t_enq = time.perf_counter() - t0
 ms = ctx.timer_stop()
 print('host enqueue: %.1f us per sweep step (GPU pass time below)' % (1e6 * t_enq / 4 / (N - 1)))
+ctx.synchronize()
+t0 = time.perf_counter()
+ctx.forward(want_f=False)
+t1 = time.perf_counter()
+ctx.sweep(ctx.l_pos == N - 1, N - 1, True, *hp, want_metrics=False, want_f=False)
+t2 = time.perf_counter()
+ctx.synchronize()
+t3 = time.perf_counter()
+print('single pass from idle: forward enqueue %.1f us, sweep enqueue %.1f us per step, drain %.1f us per step'
+      % (1e6 * (t1 - t0), 1e6 * (t2 - t1) / (N - 1), 1e6 * (t3 - t2) / (N - 1)))
 print('pass: %.3f ms  -> %.1f us per sweep step (incl. forward)' % (ms / 4, 1e3 * ms / 4 / (N - 1)))
 # stamps of the last step of a full-speed sweep (stops half way so that the last step is an interior one)
 ctx.debug_enable(2)
