@@ -149,6 +149,13 @@ int tnml_svd_split(tnml_ctx *ctx, const float *mat, int rows, int cols, int m, f
  * 1e-8 costs one more and reaches ~1e-6.  Allowed range [1e-12, 1e-2]. */
 int tnml_set_svd_stop(tnml_ctx *ctx, double stop2);
 
+/* The batch-independent part of a step (update_B's tail, compute_L2_reg, tensor_svd) runs in one
+ * workgroup's LDS when the merged tensor fits (min(rows, cols) <= 64 and <= 160 KB of LDS: bond <= 32 at
+ * two labels) and through HBM-resident kernels otherwise (min(rows, cols) <= 128: bond 50 with ten labels).
+ * force_large = 1 sends every step down the second path (tests, diagnostics); 0 restores the automatic
+ * choice.  Environment variable TNML_NARROW=big does the same for a whole process. */
+int tnml_set_narrow_path(tnml_ctx *ctx, int force_large);
+
 /* Network.apply_act_func / compute_loss_derivate on the device-resident f (:767-835);
  * act_out, lossder_out [L][b], either may be NULL.  input_is_activated != 0: f already went
  * through the activation (what compute_loss_derivate receives, :800), only the derivative runs. */

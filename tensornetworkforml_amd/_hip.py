@@ -26,7 +26,7 @@ SYMBOLS = [
     'tnml_set_f', 'tnml_get_f', 'tnml_sweep', 'tnml_activation', 'tnml_get_env', 'tnml_debug_enable',
     'tnml_get_step_debug', 'tnml_l_pos', 'tnml_batch', 'tnml_timer_start', 'tnml_timer_stop',
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
-    'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop',
+    'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path',
 ]
 
 
@@ -87,6 +87,7 @@ def lib():
                                     f64p, C.c_size_t, f32p]
         L.tnml_l2_term.argtypes = [vp, f32p, C.c_int, C.c_float, f64p, f64p, C.c_size_t]
         L.tnml_set_svd_stop.argtypes = [vp, C.c_double]
+        L.tnml_set_narrow_path.argtypes = [vp, C.c_int]
         L.tnml_svd_split.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f64p]
         _lib = L
     return _lib
@@ -293,6 +294,10 @@ class Context:
     def set_svd_stop(self, stop2):
         """Jacobi stopping threshold on g^2 / scale^2 (include/tnml.h); default 1e-6."""
         _chk(lib().tnml_set_svd_stop(self._h, float(stop2)))
+
+    def set_narrow_path(self, force_large):
+        """True: every step takes the large-tensor (HBM-resident) path; False: automatic."""
+        _chk(lib().tnml_set_narrow_path(self._h, int(bool(force_large))))
 
     def debug_enable(self, on=True):
         """True / 1: capture every step's tensors; 2: cycle stamps only; False / 0: off."""

@@ -1,0 +1,60 @@
+// Device-side pieces of the two-sided Jacobi eigenvalue iteration shared by the in-LDS step kernel
+// (kernels_narrow.hip, n <= 64) and the large-tensor path (kernels_big.hip, n <= 128).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tnml {
+
+constexpr int kJacobiMaxSweeps = 30;
+
+// Rotation (c, s) that annihilates g in [[a, g], [g, b]] under J = [[c, s], [-s, c]] (columns:
+// a' = c a - s b, b' = s a + c b).  level: 0 negligible (identity), 1 small, 2 large -- the sweep
+// loop stops once a whole sweep made only small rotations (quadratic convergence then leaves
+// off-diagonals below the tolerance).
+// Convergence thresholds of the Jacobi iteration, all on g^2 / scale2 with
+//   scale2 = max(a b, (kKeptFrac * lambda_m)^2),   lambda_m = m-th largest diagonal entry:
+// diagonal entries far below the smallest eigenvalue that is KEPT are treated as if they were at
+// that level, i.e. the discarded cluster is not resolved to high relative accuracy (it only has to
+// be separated from the kept subspace).  Emulated on headline-shaped matrices: 7.5 sweeps instead
+// of 9.4, truncated product within 2e-8 of LAPACK's (tools/jacobi_emulation.py).
+constexpr double kJacobiTol2 = 1e-14;     // below: pair left alone
+// "big" rotation: g^2 / scale2 above NarrowParams::svd_stop2 (default kJacobiStop2).  A sweep without one ends
+// the iteration: quadratic convergence then leaves off-diagonals of relative size ~svd_stop2.  Measured on
+// the merged tensors of a C3-shaped run (tools/jacobi_correction_emulation.py, probe_svd_accuracy.py):
+//   svd_stop2   sweeps (n = 40)   worst |A.C - best rank-m| / max|B|   worst relative error of a kept sigma
+//   1e-4        3.9               2e-4                                  5e-6
+//   1e-6        5.0               6e-6                                  7e-11
+//   1e-8        5.9               1e-6                                  8e-12
+constexpr double kKeptFrac = 0.2;
+constexpr double kJacobiAbs = 1e-15;      // |g| / trace floor: eigenvalues under 1e-15 trace are float32 noise of B
+
+// Rotation J = [[c, s], [-s, c]] annihilating g in [[a, g], [g, b]] (columns: a' = c a - s b,
+// b' = s a + c b); t = s / c.  G is pre-scaled to trace ~ 1, so the float evaluation of
+// t = 2g / (d + sign(d) sqrt(d^2 + 4 g^2)) can neither overflow nor (above the floor) underflow;
+// c is refined to float64 by one Newton step on rsqrt so that c^2 + s^2 = 1 to ~1e-14.
+struct Rot { double c, s, t; int level; };
+__device__ inline Rot jacobi_rot(double a, double b, double g, double kept2, double abs2, double big2) {
+  Rot r; r.c = 1.0; r.s = 0.0; r.t = 0.0; r.level = 0;
+  const double g2 = g * g;
+  const double sc = fmax(fabs(a * b), kept2);
+  const bool act = g2 > fmax(kJacobiTol2 * sc, abs2);          // false for g == 0 and NaN
+  const float df = (float)(b - a), gf = (float)g;
+  const float hyp = __builtin_amdgcn_sqrtf(fmaf(df, df, 4.f * gf * gf));
+  const float t = 2.f * gf * __builtin_amdgcn_rcpf(df + copysignf(hyp, df));
+  const double td = (double)t;
+  const double x = fma(td, td, 1.0);                           // in [1, 2]
+  double c0 = (double)__builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
+  c0 = c0 * fma(-0.5 * x, c0 * c0, 1.5);
+  if (act) { r.c = c0; r.s = c0 * td; r.t = td; r.level = (g2 > big2 * sc) ? 2 : 1; }
+  return r;
+}
+
+// one-lane wave shift of a double: CTRL 0x138 = wave_shr:1 (lane i receives lane i-1), 0x130 = wave_shl:1
+template <int CTRL> __device__ inline double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+}  // namespace tnml

@@ -1,0 +1,525 @@
+// Large-tensor path of the sweep step's batch-independent part: the same arithmetic as
+// narrow_step_kernel (kernels_narrow.hip), for merged tensors that do not fit one workgroup's LDS or
+// whose short side exceeds 64 (C5 of BASELINE.json: bond 50, 10 labels -> a 100 x 1000 merged tensor,
+// 400 KB in float32).  The merged tensor, the weight-decay term and the update live in HBM and are
+// produced by many-workgroup kernels; only the Jacobi eigenvalue iteration on the n x n Gram matrix
+// (n <= 128) runs in a single workgroup, with the symmetric matrix packed as upper-triangular 2x2
+// blocks (two LDS buffers of np(np+1)/2 blocks: 82 KB at n = 100).  The eigenvectors are never formed
+// in that kernel: it logs every rotation (c, s), and a replay kernel applies the log to the n unit
+// vectors AND to the `len` columns of the matricised tensor, one wavefront per vector (pair k on lane k,
+// the tournament move as DPP wave shifts), which yields V and W^T V -- the two SVD factors up to the
+// sigma^(+-1/2) scaling -- without any further GEMM.
+//
+// Reference lines: update_B Network_class.py:577-763, compute_L2_reg :966-1179, tensor_svd :839-962.
+#include <algorithm>
+
+#include "tnml_internal.h"
+#include "jacobi_device.h"
+
+namespace tnml {
+
+namespace {
+
+constexpr int kBT = 256;   // threads of the element-wise kernels
+
+// ---- merged tensor B[h,dk,dk1,g,l] = sum_s lab(h,dk,s,l) pl(s,dk1,g)  (Network_class.py:484) ----------------
+__global__ __launch_bounds__(kBT) void big_merge_kernel(NarrowParams p, float *__restrict__ Bf) {
+  const int D = kD, g = p.g, s = p.s, L = p.L;
+  for (int e = blockIdx.x * kBT + threadIdx.x; e < p.bsize; e += gridDim.x * kBT) {
+    const int l = e % L;
+    int q = e / L;
+    const int g_ = q % g; q /= g;
+    const int dk1 = q % D; q /= D;
+    const int dk = q % D, h_ = q / D;
+    const float *la = p.lab.base + h_ * p.lab.s_in + dk * p.lab.s_d + l;
+    const float *pl = p.pl.base + dk1 * p.pl.s_d + g_ * p.pl.s_out;
+    double acc = 0.0;
+    for (int k = 0; k < s; ++k) acc += (double)la[k * p.lab.s_out] * (double)pl[k * p.pl.s_in];
+    Bf[e] = (float)acc;
+  }
+}
+
+// ---- T[e_, rest] = sum_a Nh[a, e_] B[a, rest]   (first half of Ln.B.Rn) --------------------------------------
+__global__ __launch_bounds__(kBT) void big_l2_T_kernel(NarrowParams p, const float *__restrict__ Bf, double *__restrict__ T) {
+  const int h = p.h, RW = p.bsize / p.h;
+  for (int e = blockIdx.x * kBT + threadIdx.x; e < p.bsize; e += gridDim.x * kBT) {
+    const int rest = e % RW, e_ = e / RW;
+    double acc = 0.0;
+    if (p.Nh) { for (int a = 0; a < h; ++a) acc += p.Nh[a * h + e_] * (double)Bf[(size_t)a * RW + rest]; }
+    else acc = (double)Bf[e];
+    T[e] = acc;
+  }
+}
+
+// ---- G = T . Ng, the weight-decay term, dv = raw - wdterm and the three block-partial sums --------------------
+//   ws layout (doubles): [0,Bs) B   [Bs,2Bs) dB_raw   [2Bs,3Bs) dv (later B_new)   [3Bs,4Bs) weight-decay term
+__global__ __launch_bounds__(kBT) void big_wd_kernel(NarrowParams p, const float *__restrict__ Bf, const double *__restrict__ T,
+                                                    double *__restrict__ ws, double *__restrict__ part) {
+  const int g = p.g, L = p.L, Bs = p.bsize;
+  double sumB = 0.0, sumD = 0.0, l2 = 0.0;
+  for (int e = blockIdx.x * kBT + threadIdx.x; e < Bs; e += gridDim.x * kBT) {
+    const double bv = (double)Bf[e];
+    const double raw = (double)p.red[e];
+    double wdterm;
+    if (p.l2_flag) {
+      const int l = e % L, q = e / L;
+      const int f_ = q % g, i = q / g;
+      double gv = 0.0;
+      if (p.Ng) { for (int c = 0; c < g; ++c) gv += T[((size_t)i * g + c) * L + l] * p.Ng[c * g + f_]; }
+      else gv = T[e];
+      l2 += bv * gv;
+      wdterm = 2.0 * (double)p.wd * gv;
+    } else {
+      wdterm = (double)p.wd * bv;
+    }
+    const double dv = raw - wdterm;
+    ws[e] = bv; ws[(size_t)Bs + e] = raw; ws[2 * (size_t)Bs + e] = dv; ws[3 * (size_t)Bs + e] = wdterm;
+    sumB += fabs(bv);
+    sumD += fabs(dv);
+  }
+  __shared__ double red[3][kBT / 64];
+  for (int off = 32; off > 0; off >>= 1) { sumB += __shfl_xor(sumB, off); sumD += __shfl_xor(sumD, off); l2 += __shfl_xor(l2, off); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sumB; red[1][threadIdx.x >> 6] = sumD; red[2][threadIdx.x >> 6] = l2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0, c = 0;
+    for (int w = 0; w < kBT / 64; ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
+    part[3 * blockIdx.x] = a; part[3 * blockIdx.x + 1] = b; part[3 * blockIdx.x + 2] = c;
+  }
+}
+
+// ---- clip + update (Network_class.py:755-761); every block sums the partials in the same fixed order ----------
+__global__ __launch_bounds__(kBT) void big_update_kernel(NarrowParams p, double *__restrict__ ws, const double *__restrict__ part,
+                                                        int nparts) {
+  const int Bs = p.bsize;
+  // identical summation tree in every block and on every rank: lanes stride the partials, then a fixed
+  // xor-shuffle tree (nparts <= 128)
+  __shared__ double sSum[3];
+  if (threadIdx.x < 64) {
+    double a_ = 0.0, b_ = 0.0, c_ = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) { a_ += part[3 * i]; b_ += part[3 * i + 1]; c_ += part[3 * i + 2]; }
+    for (int off = 32; off > 0; off >>= 1) { a_ += __shfl_xor(a_, off); b_ += __shfl_xor(b_, off); c_ += __shfl_xor(c_, off); }
+    if (threadIdx.x == 0) { sSum[0] = a_; sSum[1] = b_; sSum[2] = c_; }
+  }
+  __syncthreads();
+  const double sumB = sSum[0], sumD = sSum[1], l2 = sSum[2];
+  double factor = (double)p.lr;
+  if (sumD > sumB) factor = (double)p.lr * (sumB / sumD);
+  for (int e = blockIdx.x * kBT + threadIdx.x; e < Bs; e += gridDim.x * kBT) {
+    const float v = (float)(ws[e] + factor * ws[2 * (size_t)Bs + e]);
+    p.Bnew[e] = v;
+    ws[2 * (size_t)Bs + e] = (double)v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (!isfinite(sumD) || !isfinite(sumB)) atomicOr(p.status, 1);
+    double *sc = ws + 4 * (size_t)Bs + kDbgSigma;
+    sc[0] = (double)p.wd * l2; sc[1] = sumB; sc[2] = sumD;
+    if (p.stop_after_update && p.metrics) {
+      const double cnt = (double)p.red[Bs + 3];
+      const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
+      p.metrics[0] = (float)((double)p.red[Bs] * inv);
+      p.metrics[1] = (float)((double)p.red[Bs + 1] * inv / (double)p.L);
+    }
+  }
+}
+
+// ---- Gram matrix of the short side, float64 accumulation of the float32 B_new -----------------------------------
+//   W(i, x) = Bn[i * si + x * sx];  G[i][j] = sum_x W(i,x) W(j,x), 16x16 output tile per block, upper tiles only
+__global__ __launch_bounds__(256) void big_gram_kernel(const float *__restrict__ Bn, int n, int len, int si, int sx,
+                                                      double *__restrict__ G) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (ti > tj) return;
+  __shared__ float sA[16][65], sB[16][65];
+  const int r = threadIdx.x >> 4, cidx = threadIdx.x & 15;
+  double acc = 0.0;
+  for (int x0 = 0; x0 < len; x0 += 64) {
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      const int row = e >> 6, x = e & 63;
+      const int ia = ti * 16 + row, ib = tj * 16 + row;
+      sA[row][x] = (ia < n && x0 + x < len) ? Bn[(size_t)ia * si + (size_t)(x0 + x) * sx] : 0.f;
+      sB[row][x] = (ib < n && x0 + x < len) ? Bn[(size_t)ib * si + (size_t)(x0 + x) * sx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int x = 0; x < 64; ++x) acc += (double)sA[r][x] * (double)sB[cidx][x];
+    __syncthreads();
+  }
+  const int i = ti * 16 + r, j = tj * 16 + cidx;
+  if (i < n && j < n && i <= j) { G[(size_t)i * n + j] = acc; G[(size_t)j * n + i] = acc; }
+}
+
+// ---- two-sided Jacobi on the packed symmetric matrix, rotations logged ------------------------------------------
+// Block (P, Q), P <= Q, of the current pairing lives at 4 doubles [e(2P,2Q), e(2P,2Q+1), e(2P+1,2Q), e(2P+1,2Q+1)]
+// (slot 2 of a diagonal block is unused).  Same schedule, look-ahead parameters and stopping rule as the
+// in-LDS kernel (kernels_narrow.hip phase 7); see there for the derivation.
+__device__ inline int blk_index(int P, int Q, int np) { return P * np - P * (P - 1) / 2 + (Q - P); }
+__device__ inline int elem_slot(int a, int b, int np) {       // element (a, b) of the symmetric matrix, any order
+  const int lo = min(a, b), hi = max(a, b);
+  return 4 * blk_index(lo >> 1, hi >> 1, np) + 2 * (lo & 1) + (hi & 1);
+}
+
+struct BigJacobiArgs {
+  const double *G;       // n x n, row-major (input)
+  int n, m;
+  double stop2;
+  double2 *rotlog;       // [round][np] (c, s)
+  double *lam;           // [n] eigenvalues (diag of the rotated matrix, original scale) by final position
+  int *info;             // [0] rounds applied, [1] sweeps, [2] converged
+  unsigned long long *counters;
+  int *status;
+};
+
+__global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, NT = 1024;
+  const int n = a.n, m = a.m, np = n / 2, ne = n;
+  const int nblk = np * (np + 1) / 2;
+  double *G0 = (double *)smem_raw, *G1 = G0 + 4 * (size_t)nblk;
+  double *dCS = G1 + 4 * (size_t)nblk;            // [2][np][4]
+  double *dRed = dCS + 8 * (size_t)np;            // 64
+  int *sPi = (int *)(dRed + 64), *sPiInv = sPi + ne, *sFlag = sPiInv + ne;
+
+  // load + trace
+  double trp = 0.0;
+  for (int b = tid; b < nblk; b += NT) {
+    int P = 0, rem = b;
+    while (rem >= np - P) { rem -= np - P; ++P; }
+    const int Q = P + rem;
+    const double e11 = a.G[(size_t)(2 * P) * n + 2 * Q], e12 = a.G[(size_t)(2 * P) * n + 2 * Q + 1];
+    const double e21 = a.G[(size_t)(2 * P + 1) * n + 2 * Q], e22 = a.G[(size_t)(2 * P + 1) * n + 2 * Q + 1];
+    G0[4 * b] = e11; G0[4 * b + 1] = e12; G0[4 * b + 2] = e21; G0[4 * b + 3] = e22;
+    if (P == Q) trp += e11 + e22;
+  }
+  for (int pos = tid; pos < ne; pos += NT) {
+    const int kq = pos >> 1;
+    int nxt;
+    if (pos & 1) nxt = (kq == 0) ? (np > 1 ? 2 : 1) : 2 * (kq - 1) + 1;
+    else nxt = (kq == 0) ? 0 : (kq == np - 1 ? 2 * kq + 1 : 2 * (kq + 1));
+    sPi[pos] = nxt;
+    sPiInv[nxt] = pos;
+  }
+  for (int off = 32; off > 0; off >>= 1) trp += __shfl_xor(trp, off);
+  if ((tid & 63) == 0) dRed[tid >> 6] = trp;
+  __syncthreads();
+  double tr = 0.0;
+  for (int w = 0; w < NT / 64; ++w) tr += dRed[w];
+  const int sc_exp = (tr > 0.0 && isfinite(tr)) ? __builtin_amdgcn_frexp_exp(tr) : 0;
+  __syncthreads();
+  for (int e = tid; e < 4 * nblk; e += NT) G0[e] = __builtin_amdgcn_ldexp(G0[e], -sc_exp);
+  __syncthreads();
+
+  auto diag = [&](const double *G, int j) { return G[4 * blk_index(j >> 1, j >> 1, np) + 3 * (j & 1)]; };
+  auto kept_scale = [&](const double *G) -> double {
+    for (int j = tid; j < n; j += NT) {
+      const double lj = diag(G, j);
+      int rank = 0;
+      for (int i = 0; i < n; ++i) { const double li = diag(G, i); rank += (li > lj) || (li == lj && i < j); }
+      if (rank == m - 1) dRed[60] = lj;
+    }
+    __syncthreads();
+    const double lm = kKeptFrac * fmax(dRed[60], 0.0);
+    return lm * lm;
+  };
+
+  // items: blocks P <= Q, up to 3 per worker thread (np <= 64: 2080 blocks on 960 threads)
+  constexpr int T0 = 64, MAXI = 3;
+  const int NW = NT - T0;
+  bool itValid[MAXI], itDiag[MAXI];
+  int itSrc[MAXI], itQ[MAXI], itP[MAXI], itD11[MAXI], itD12[MAXI], itD21[MAXI], itD22[MAXI];
+#pragma unroll
+  for (int u = 0; u < MAXI; ++u) {
+    const int it = (tid - T0) + u * NW;
+    itValid[u] = tid >= T0 && it < nblk;
+    int P = 0, Q = 0;
+    if (itValid[u]) {
+      int rem = it;
+      while (rem >= np - P) { rem -= np - P; ++P; }
+      Q = P + rem;
+    }
+    const int c1 = sPi[2 * Q], c2 = sPi[2 * Q + 1], o1 = sPi[2 * P], o2 = sPi[2 * P + 1];
+    itSrc[u] = 4 * blk_index(P, Q, np);
+    itQ[u] = 4 * Q; itP[u] = 4 * P;
+    itDiag[u] = P == Q;
+    itD11[u] = elem_slot(o1, c1, np); itD12[u] = elem_slot(o1, c2, np);
+    itD21[u] = elem_slot(o2, c1, np); itD22[u] = elem_slot(o2, c2, np);
+  }
+  const double abs2 = kJacobiAbs * kJacobiAbs;
+  const bool isParam = tid < np;
+  int pa = 0, pb = 1;
+  if (isParam) { pa = sPiInv[2 * tid]; pb = sPiInv[2 * tid + 1]; }
+  const int pA = pa >> 1, ra = pa & 1, pB = pb >> 1, rb = pb & 1;
+  const int slotAA = 4 * blk_index(pA, pA, np), slotBB = 4 * blk_index(pB, pB, np);
+  const int slotAB = 4 * blk_index(min(pA, pB), max(pA, pB), np);
+
+  int sweeps = 0, converged = 0, cur = 0, rounds = 0;
+  double *Gc = G0, *Gn = G1;
+  double kept2 = 0.0;
+  if (n > 1) {
+    kept2 = kept_scale(Gc);
+    if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; }
+    if (isParam) {
+      const int sl = 4 * blk_index(tid, tid, np);
+      const Rot r = jacobi_rot(Gc[sl], Gc[sl + 3], Gc[sl + 1], kept2, abs2, a.stop2);
+      double *o = dCS + (cur * np + tid) * 4;
+      o[0] = r.c; o[1] = r.s; o[2] = r.t;
+      a.rotlog[tid] = make_double2(r.c, r.s);
+      if (r.level >= 1) sFlag[0] = 1;
+      if (r.level >= 2) sFlag[1] = 1;
+    }
+    __syncthreads();
+    for (; sweeps < kJacobiMaxSweeps; ++sweeps) {
+      for (int rnd = 0; rnd < ne - 1; ++rnd) {
+        const double *csc = dCS + cur * np * 4;
+        if (isParam) {
+          const double2 csA = *reinterpret_cast<const double2 *>(csc + 4 * pA);
+          const double2 csB = *reinterpret_cast<const double2 *>(csc + 4 * pB);
+          const double tA = csc[4 * pA + 2], tB = csc[4 * pB + 2];
+          const double2 dA = *reinterpret_cast<const double2 *>(Gc + slotAA);
+          const double bA = Gc[slotAA + 3];
+          const double2 dB = *reinterpret_cast<const double2 *>(Gc + slotBB);
+          const double bB = Gc[slotBB + 3];
+          double2 r0, r1;
+          if (pA < pB) {
+            r0 = *reinterpret_cast<const double2 *>(Gc + slotAB);
+            r1 = *reinterpret_cast<const double2 *>(Gc + slotAB + 2);
+          } else if (pA > pB) {
+            const double2 s0 = *reinterpret_cast<const double2 *>(Gc + slotAB);
+            const double2 s1 = *reinterpret_cast<const double2 *>(Gc + slotAB + 2);
+            r0 = make_double2(s0.x, s1.x);
+            r1 = make_double2(s0.y, s1.y);
+          } else {
+            r0 = dA;
+            r1 = make_double2(dA.y, bA);
+          }
+          const double na = ra ? fma(tA, dA.y, bA) : fma(-tA, dA.y, dA.x);
+          const double nb = rb ? fma(tB, dB.y, bB) : fma(-tB, dB.y, dB.x);
+          const double h0 = ra ? fma(csA.y, r0.x, csA.x * r1.x) : fma(csA.x, r0.x, -csA.y * r1.x);
+          const double h1 = ra ? fma(csA.y, r0.y, csA.x * r1.y) : fma(csA.x, r0.y, -csA.y * r1.y);
+          const double ng = rb ? fma(csB.y, h0, csB.x * h1) : fma(csB.x, h0, -csB.y * h1);
+          const Rot r = jacobi_rot(na, nb, ng, kept2, abs2, a.stop2);
+          double *o = dCS + ((cur ^ 1) * np + tid) * 4;
+          o[0] = r.c; o[1] = r.s; o[2] = r.t;
+          a.rotlog[(size_t)(rounds + 1) * np + tid] = make_double2(r.c, r.s);
+          if (r.level >= 1) sFlag[0] = 1;
+          if (r.level >= 2) sFlag[1] = 1;
+        }
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+          if (!itValid[u]) continue;
+          const double2 csq = *reinterpret_cast<const double2 *>(csc + itQ[u]);
+          const double2 csp = *reinterpret_cast<const double2 *>(csc + itP[u]);
+          const double2 r0 = *reinterpret_cast<const double2 *>(Gc + itSrc[u]);
+          double2 r1 = *reinterpret_cast<const double2 *>(Gc + itSrc[u] + 2);
+          if (itDiag[u]) r1.x = r0.y;
+          const double h11 = csp.x * r0.x - csp.y * r1.x, h12 = csp.x * r0.y - csp.y * r1.y;
+          const double h21 = csp.y * r0.x + csp.x * r1.x, h22 = csp.y * r0.y + csp.x * r1.y;
+          double n11 = csq.x * h11 - csq.y * h12, n12 = csq.y * h11 + csq.x * h12;
+          double n21 = csq.x * h21 - csq.y * h22, n22 = csq.y * h21 + csq.x * h22;
+          if (itDiag[u] && csq.y != 0.0) { n12 = 0.0; n21 = 0.0; }
+          Gn[itD11[u]] = n11; Gn[itD12[u]] = n12;
+          if (!itDiag[u]) Gn[itD21[u]] = n21;
+          Gn[itD22[u]] = n22;
+        }
+        __syncthreads();
+        double *tsw = Gc; Gc = Gn; Gn = tsw;
+        cur ^= 1;
+        ++rounds;
+      }
+      const int any_rot = sFlag[0], big_rot = sFlag[1];
+      __syncthreads();
+      if (!any_rot || !big_rot) { converged = 1; ++sweeps; break; }
+      if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; }
+      kept2 = kept_scale(Gc);
+    }
+  } else {
+    converged = 1;
+  }
+  for (int j = tid; j < n; j += NT) a.lam[j] = __builtin_amdgcn_ldexp(fmax(diag(Gc, j), 0.0), sc_exp);
+  if (tid == 0) {
+    a.info[0] = rounds; a.info[1] = sweeps; a.info[2] = converged;
+    if (a.counters) {
+      atomicAdd(a.counters, (unsigned long long)sweeps);
+      atomicAdd(a.counters + 1, 1ull);
+      atomicAdd(a.counters + 2, (unsigned long long)rounds);
+    }
+    if (!converged) atomicOr(a.status, 2);
+  }
+}
+
+// ---- replay of the rotation log: one wavefront per vector, pair k on lane k --------------------------------------
+//   vector v < n: unit vector e_v (-> row v of V);  v >= n: column x = v - n of W (-> row x of W^T V)
+__global__ __launch_bounds__(64) void big_replay_kernel(const float *__restrict__ Bn, int n, int len, int si, int sx,
+                                                       const double2 *__restrict__ rotlog, const int *__restrict__ info,
+                                                       double *__restrict__ VW) {
+  const int v = blockIdx.x, k = threadIdx.x, np = n / 2;
+  const int kk = k < np ? k : np - 1;
+  double top, bot;
+  if (v < n) { top = (2 * kk == v) ? 1.0 : 0.0; bot = (2 * kk + 1 == v) ? 1.0 : 0.0; }
+  else {
+    const size_t x = (size_t)(v - n) * sx;
+    top = (double)Bn[(size_t)(2 * kk) * si + x];
+    bot = (double)Bn[(size_t)(2 * kk + 1) * si + x];
+  }
+  const int T = info[0];
+  // the log is read eight rounds at a time, the next chunk in flight while this one is applied
+  constexpr int CH = 8;
+  double2 nxt[CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) nxt[u] = u < T ? rotlog[(size_t)u * np + kk] : make_double2(1.0, 0.0);
+  for (int r0 = 0; r0 < T; r0 += CH) {
+    double2 curc[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) curc[u] = nxt[u];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int rr = r0 + CH + u;
+      nxt[u] = rr < T ? rotlog[(size_t)rr * np + kk] : make_double2(1.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      if (r0 + u >= T) break;                     // wave-uniform
+      const double2 cs = curc[u];
+      const double nt = cs.x * top - cs.y * bot, nb = cs.y * top + cs.x * bot;
+      if (np > 1) {
+        const double t1 = dpp_f64<0x138>(nt), b1 = dpp_f64<0x138>(nb), c1 = dpp_f64<0x130>(nb);
+        top = k == 0 ? nt : (k == 1 ? b1 : t1);
+        bot = k == np - 1 ? nt : c1;
+      } else {
+        top = nt; bot = nb;
+      }
+    }
+  }
+  if (k < np) {
+    VW[(size_t)v * n + 2 * k] = top;
+    VW[(size_t)v * n + 2 * k + 1] = bot;
+  }
+}
+
+// ---- eigenvalue order, the two new cores, metrics ---------------------------------------------------------------
+__global__ __launch_bounds__(1024) void big_finish_kernel(NarrowParams p, const double *__restrict__ lam, const double *__restrict__ VW,
+                                                         const int *__restrict__ info, double *__restrict__ ws, float *__restrict__ Cb) {
+  __shared__ double sLam[128], sSq[2][128];
+  __shared__ int sOrd[128];
+  const int tid = threadIdx.x, NT = 1024;
+  const int D = kD, h = p.h, g = p.g, L = p.L, m = p.m, Bs = p.bsize;
+  const int r = D * h, c = D * g * L;
+  const bool short_rows = r <= c;
+  const int n = short_rows ? r : c, len = short_rows ? c : r;
+  for (int j = tid; j < n; j += NT) sLam[j] = lam[j];
+  __syncthreads();
+  for (int j = tid; j < n; j += NT) {
+    const double lj = sLam[j];
+    int rank = 0;
+    for (int i = 0; i < n; ++i) { const double li = sLam[i]; rank += (li > lj) || (li == lj && i < j); }
+    sOrd[rank] = j;
+    ws[4 * (size_t)Bs + rank] = sqrt(lj);
+  }
+  __syncthreads();
+  const double lam_max = sLam[sOrd[0]];
+  for (int sp = tid; sp < m; sp += NT) {
+    const double l_ = sLam[sOrd[sp]];
+    const bool ok = l_ > 1e-300 && l_ > 1e-30 * lam_max;
+    const double sq = ok ? sqrt(sqrt(l_)) : 0.0;
+    sSq[0][sp] = sq; sSq[1][sp] = ok ? 1.0 / sq : 0.0;
+  }
+  __syncthreads();
+  // short-side factor: V[kk][pos_j] sigma_j^(1/2)
+  for (int e = tid; e < n * m; e += NT) {
+    const int kk = e / m, sp = e % m;
+    const float v = (float)(VW[(size_t)kk * n + sOrd[sp]] * sSq[0][sp]);
+    if (short_rows) {
+      Cb[kk * m + sp] = v;
+      p.out_behind[(kk / D) * p.ob_s_h + (kk % D) * p.ob_s_d + sp * p.ob_s_m] = v;
+    } else {
+      const int l = kk % L, q = kk / L;
+      p.out_ahead[sp * p.oa_s_m + (q / g) * p.oa_s_d + (q % g) * p.oa_s_g + l] = v;
+    }
+  }
+  // long-side factor: (W^T V)[x][pos_j] sigma_j^(-1/2)
+  for (int e = tid; e < len * m; e += NT) {
+    const int x = e / m, sp = e % m;
+    const float v = (float)(VW[(size_t)(n + x) * n + sOrd[sp]] * sSq[1][sp]);
+    if (short_rows) {            // x = (dk1, g_, l)
+      const int l = x % L, q = x / L;
+      p.out_ahead[sp * p.oa_s_m + (q / g) * p.oa_s_d + (q % g) * p.oa_s_g + l] = v;
+    } else {                     // x = (h_, dk)
+      Cb[x * m + sp] = v;
+      p.out_behind[(x / D) * p.ob_s_h + (x % D) * p.ob_s_d + sp * p.ob_s_m] = v;
+    }
+  }
+  if (tid == 0) {
+    double *sc = ws + 4 * (size_t)Bs + kDbgSigma;
+    sc[3] = (double)info[1];
+    sc[4] = (double)n;
+    if (p.metrics) {
+      const double cnt = (double)p.red[Bs + 3];
+      const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
+      p.metrics[0] = (float)((double)p.red[Bs] * inv);
+      p.metrics[1] = (float)((double)p.red[Bs + 1] * inv / (double)L);
+      if (p.red[Bs + 2] != 0.f) atomicOr(p.status, 1);
+    }
+  }
+}
+
+// ---- behind norm environment of the next step: Nh_new = Cb^T (Nh (x) 1_d) Cb -----------------------------------
+__global__ __launch_bounds__(kBT) void big_norm_T_kernel(NarrowParams p, const float *__restrict__ Cb, double *__restrict__ T2) {
+  const int D = kD, h = p.h, m = p.m, DM = D * m;
+  for (int e = blockIdx.x * kBT + threadIdx.x; e < h * DM; e += gridDim.x * kBT) {
+    const int j = e % DM, i = e / DM;
+    double acc = 0.0;
+    if (p.Nh) { for (int kk = 0; kk < h; ++kk) acc += p.Nh[i * h + kk] * (double)Cb[(size_t)kk * DM + j]; }
+    else acc = (double)Cb[e];
+    T2[e] = acc;
+  }
+}
+__global__ __launch_bounds__(kBT) void big_norm_out_kernel(NarrowParams p, const float *__restrict__ Cb, const double *__restrict__ T2) {
+  const int D = kD, h = p.h, m = p.m;
+  for (int e = blockIdx.x * kBT + threadIdx.x; e < m * m; e += gridDim.x * kBT) {
+    const int j = e % m, i = e / m;
+    double acc = 0.0;
+    for (int kk = 0; kk < h * D; ++kk) acc += (double)Cb[(size_t)kk * m + i] * T2[(size_t)kk * m + j];
+    p.Nh_new[e] = acc;
+  }
+}
+
+}  // namespace
+
+size_t big_jacobi_lds_bytes(int n) {
+  const int np = n / 2;
+  const size_t nblk = (size_t)np * (np + 1) / 2;
+  return (8 * nblk + 8 * (size_t)np + 64) * sizeof(double) + (2 * (size_t)n + 8) * sizeof(int) + 16;
+}
+
+void launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st) {
+  const int D = kD, Bs = p.bsize;
+  const int r = D * p.h, c = D * p.g * p.L;
+  const bool short_rows = r <= c;
+  const int n = short_rows ? r : c, len = short_rows ? c : r;
+  const int si = short_rows ? c : 1, sx = short_rows ? 1 : c;
+  const int nb = std::min((Bs + kBT - 1) / kBT, 128);
+  const float *Bf = p.Bdirect;
+  if (!Bf) {
+    hipLaunchKernelGGL(big_merge_kernel, dim3(nb), dim3(kBT), 0, st, p, s.Bf);
+    Bf = s.Bf;
+  }
+  double *ws = p.dbg;                          // the capture block doubles as the workspace of this path
+  if (p.l2_flag) hipLaunchKernelGGL(big_l2_T_kernel, dim3(nb), dim3(kBT), 0, st, p, Bf, s.T);
+  hipLaunchKernelGGL(big_wd_kernel, dim3(nb), dim3(kBT), 0, st, p, Bf, s.T, ws, s.part);
+  hipLaunchKernelGGL(big_update_kernel, dim3(nb), dim3(kBT), 0, st, p, ws, s.part, nb);
+  if (p.stop_after_update) return;
+  const int nt = (n + 15) / 16;
+  hipLaunchKernelGGL(big_gram_kernel, dim3(nt, nt), dim3(256), 0, st, p.Bnew, n, len, si, sx, s.gram);
+  BigJacobiArgs a{};
+  a.G = s.gram; a.n = n; a.m = p.m; a.stop2 = p.svd_stop2; a.rotlog = s.rotlog; a.lam = s.lam; a.info = s.info;
+  a.counters = p.counters; a.status = p.status;
+  hipLaunchKernelGGL(big_jacobi_kernel, dim3(1), dim3(1024), big_jacobi_lds_bytes(n), st, a);
+  hipLaunchKernelGGL(big_replay_kernel, dim3(n + len), dim3(64), 0, st, p.Bnew, n, len, si, sx, s.rotlog, s.info, s.VW);
+  hipLaunchKernelGGL(big_finish_kernel, dim3(1), dim3(1024), 0, st, p, s.lam, s.VW, s.info, ws, s.Cb);
+  if (p.Nh_new) {
+    const int nb2 = std::min((p.h * D * p.m + kBT - 1) / kBT, 256);
+    hipLaunchKernelGGL(big_norm_T_kernel, dim3(nb2), dim3(kBT), 0, st, p, s.Cb, s.T2);
+    hipLaunchKernelGGL(big_norm_out_kernel, dim3(std::min((p.m * p.m + kBT - 1) / kBT, 256)), dim3(kBT), 0, st, p, s.Cb, s.T2);
+  }
+}
+
+}  // namespace tnml

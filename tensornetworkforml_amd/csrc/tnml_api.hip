@@ -74,6 +74,9 @@ struct tnml_ctx {
   double *Ln = nullptr, *Rn = nullptr;
   float *Bnew = nullptr, *slabs = nullptr, *red = nullptr, *metrics = nullptr, *scal = nullptr;
   float *Bscr = nullptr, *Bscr2 = nullptr;   // scratch merged tensors of the standalone entry points
+  BigScratch big{};                          // HBM scratch of the large-tensor path, allocated on first use
+  bool big_ready = false;
+  bool force_big = false;                    // tnml_set_narrow_path
   int slab_stride = 0, nblk_cap = 0, metrics_cap = 0;
   double *dbg = nullptr;
   size_t dbg_elems = 0;
@@ -187,7 +190,7 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   c->metrics_cap = N;
   HIP_TRY(hipMalloc(&c->metrics, (size_t)c->metrics_cap * 2 * sizeof(float)));
   HIP_TRY(hipMalloc(&c->scal, 64 * sizeof(float)));
-  c->dbg_elems = 4 * c->bmax + 64 + 48;   // 4 tensors, sigma[64], 5 scalars, stamps
+  c->dbg_elems = 4 * c->bmax + kDbgSigma + 48;   // 4 tensors, sigma[kDbgSigma], 5 scalars, stamps
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
   HIP_TRY(hipMalloc(&c->status, sizeof(int)));
   HIP_TRY(hipMemsetAsync(c->status, 0, sizeof(int), c->stream));
@@ -208,7 +211,8 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
   void *ptrs[] = {c->X, c->Xstage, c->y, c->f, c->ftmp, c->ftmp2, c->Lenv, c->Renv, c->cores, c->lab[0], c->lab[1],
-                  c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2};
+                  c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2,
+                  c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -530,6 +534,51 @@ extern "C" int tnml_activation(tnml_ctx *c, int act_fn, int loss_fn, float T, in
 // ---------------------------------------------------------------------------------------------
 // norm environments of the side a sweep runs towards (only when not inherited from the last sweep)
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// narrow step: in-LDS kernel, or the large-tensor path when the merged tensor does not fit
+// ---------------------------------------------------------------------------------------------
+static int ensure_big(tnml_ctx *c) {
+  if (c->big_ready) return TNML_OK;
+  const size_t rows_cols = (size_t)c->D * c->Mmax * (1 + c->L);
+  HIP_TRY(hipMalloc(&c->big.Bf, c->bmax * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->big.T, c->bmax * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->big.part, 3 * 128 * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->big.gram, (size_t)kBigMaxN * kBigMaxN * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->big.rotlog, ((size_t)30 * (kBigMaxN - 1) + 2) * (kBigMaxN / 2) * sizeof(double2)));
+  HIP_TRY(hipMalloc(&c->big.lam, kBigMaxN * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->big.info, 4 * sizeof(int)));
+  HIP_TRY(hipMalloc(&c->big.VW, rows_cols * kBigMaxN * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->big.Cb, rows_cols * c->Mmax * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->big.T2, rows_cols * c->Mmax * sizeof(double)));
+  c->big_ready = true;
+  return TNML_OK;
+}
+
+// which path a step of these dimensions takes: 0 in-LDS, 1 large-tensor, <0 error already reported
+static int narrow_path(const tnml_ctx *c, int h, int g, int s, int L, int m) {
+  static const bool env_big = getenv("TNML_NARROW") && std::string(getenv("TNML_NARROW")) == "big";
+  const bool force_big = env_big || c->force_big;
+  const int r = kD * h, cc = kD * g * L, nn = std::min(r, cc);
+  const size_t lds = narrow_lds_bytes(h, g, s, L, m);
+  if (!force_big && nn <= 64 && lds <= 160 * 1024) return 0;
+  if (nn > kBigMaxN)
+    return fail(TNML_ERR_ARG, "min(rows, cols) = %d > %d: the Jacobi kernels handle n <= %d", nn, kBigMaxN, kBigMaxN);
+  if (nn % 2) return fail(TNML_ERR_ARG, "odd matrix side %d", nn);
+  return 1;
+}
+
+static int run_narrow(tnml_ctx *c, NarrowParams &n, int path) {
+  if (path == 0) {
+    launch_narrow(n, narrow_lds_bytes(n.h, n.g, n.s, n.L, n.m), c->stream);
+    return TNML_OK;
+  }
+  int rc = ensure_big(c);
+  if (rc) return rc;
+  n.dbg = c->dbg;                       // the capture block is this path's workspace
+  launch_narrow_big(n, c->big, c->stream);
+  return TNML_OK;
+}
+
 static int build_norm_chain(tnml_ctx *c, bool right_side) {
   // right_side: Rn[i] for i = N-1 .. 1 (sites i..N-1);  else Ln[i] for i = 0 .. N-2 (sites 0..i)
   const int N = c->N, D = c->D;
@@ -652,9 +701,8 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       return fail(TNML_ERR_ARG, "step at sites (%d,%d) exceeds the buffers sized for M = %d", p, p + 1, c->Mmax);
     if ((size_t)h * D * m > c->core_stride || (size_t)m * D * g * L > c->lab_elems)
       return fail(TNML_ERR_ARG, "new cores at sites (%d,%d) exceed the buffers sized for M = %d", p, p + 1, c->Mmax);
-    if (nn > 64) return fail(TNML_ERR_ARG, "min(rows, cols) = %d > 64: this build's in-LDS Jacobi handles n <= 64", nn);
-    const size_t lds = narrow_lds_bytes(h, g, s, L, m);
-    if (lds > 160 * 1024) return fail(TNML_ERR_ARG, "merged tensor needs %zu B of LDS (> 160 KiB)", lds);
+    const int npath = narrow_path(c, h, g, s, L, m);
+    if (npath < 0) return npath;
 
     // ---- wide kernel -----------------------------------------------------------------------
     WideParams w{};
@@ -693,7 +741,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       const int gs = left_dir ? p - 1 : p + 2;
       w.Gcur = (gs >= 0 && gs <= N - 1) ? c->env_slot(ahe, gs) : nullptr;
     }
-    w.stamps = c->stamps ? c->dbg + 4 * c->bmax + 64 + 5 + 17 : nullptr;
+    w.stamps = c->stamps ? c->dbg + 4 * c->bmax + kDbgSigma + 5 + 17 : nullptr;
     prof_begin(c);
     launch_wide(w, nblk, c->stream);
     prof_end(c, 1);
@@ -736,11 +784,11 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     n.svd_stop2 = c->svd_stop2;
     n.stop_after_update = mode == 1;
     if (mode == 1) { n.Bnew = c->Bscr2; n.Nh_new = nullptr; }
-    n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + 64 + 5 : nullptr;
+    n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + kDbgSigma + 5 : nullptr;
     n.status = c->status;
     n.counters = c->counters;
     prof_begin(c);
-    launch_narrow(n, lds, c->stream);
+    { int rc = run_narrow(c, n, npath); if (rc) return rc; }
     prof_end(c, 3);
     {   // diagnostic: TNML_EXTRA_LAUNCHES=k adds k trivial dependent launches per step (prices a boundary)
       static const int extra = getenv("TNML_EXTRA_LAUNCHES") ? atoi(getenv("TNML_EXTRA_LAUNCHES")) : 0;
@@ -871,8 +919,8 @@ extern "C" int tnml_l2_term(tnml_ctx *c, const float *B_canon, int left_dir, flo
   const size_t bsize = (size_t)ml * D * D * mr * L;
   if (capacity < bsize) return fail(TNML_ERR_ARG, "capacity too small");
   if (bsize > c->bmax) return fail(TNML_ERR_ARG, "merged tensor exceeds the buffers sized for M = %d", c->Mmax);
-  const size_t lds = narrow_lds_bytes(h, g, 1, L, 1);
-  if (lds > 160 * 1024) return fail(TNML_ERR_ARG, "merged tensor needs %zu B of LDS (> 160 KiB)", lds);
+  const int npath = narrow_path(c, h, g, 1, L, 1);
+  if (npath < 0) return npath;
   int rc = norm_envs_for_label_site(c);
   if (rc) return rc;
   std::vector<float> rel(bsize);
@@ -891,7 +939,8 @@ extern "C" int tnml_l2_term(tnml_ctx *c, const float *B_canon, int left_dir, flo
   n.dbg = c->dbg; n.status = c->status; n.counters = nullptr;
   n.Bdirect = c->Bscr; n.stop_after_update = 1;
   n.svd_stop2 = c->svd_stop2;
-  launch_narrow(n, lds, c->stream);
+  rc = run_narrow(c, n, npath);
+  if (rc) return rc;
   HIP_TRY(hipGetLastError());
   c->last_bsize = (int)bsize; c->last_n = 1; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
   const bool dbg_was = c->debug;
@@ -914,11 +963,10 @@ extern "C" int tnml_svd_split(tnml_ctx *c, const float *mat, int rows, int cols,
   const int h = rows / D, g = cols / D, nn = std::min(rows, cols);
   if (m < 1 || m > nn) return fail(TNML_ERR_ARG, "kept rank %d outside [1, %d]", m, nn);
   const size_t bsize = (size_t)rows * cols;
-  if (nn > 64) return fail(TNML_ERR_ARG, "min(rows, cols) = %d > 64: this build's in-LDS Jacobi handles n <= 64", nn);
   if (bsize > c->bmax || (size_t)rows * m > c->bmax || (size_t)m * cols > c->bmax)
     return fail(TNML_ERR_ARG, "matrix exceeds the buffers sized for M = %d", c->Mmax);
-  const size_t lds = narrow_lds_bytes(h, g, 1, 1, m);
-  if (lds > 160 * 1024) return fail(TNML_ERR_ARG, "matrix needs %zu B of LDS (> 160 KiB)", lds);
+  const int npath = narrow_path(c, h, g, 1, 1, m);
+  if (npath < 0) return npath;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(c->Bscr, mat, bsize * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(c->red, 0, (size_t)c->slab_stride * sizeof(float), c->stream));
@@ -934,13 +982,13 @@ extern "C" int tnml_svd_split(tnml_ctx *c, const float *mat, int rows, int cols,
   n.dbg = c->dbg; n.status = c->status; n.counters = c->counters;
   n.Bdirect = c->Bscr;
   n.svd_stop2 = c->svd_stop2;
-  launch_narrow(n, lds, c->stream);
+  { int rc = run_narrow(c, n, npath); if (rc) return rc; }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(US, us_dev, (size_t)rows * m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(SVh, svh_dev, (size_t)m * cols * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (sigma) {
-    std::vector<double> sg(64);
+    std::vector<double> sg(kBigMaxN);
     HIP_TRY(hipMemcpy(sg.data(), c->dbg + 4 * bsize, nn * sizeof(double), hipMemcpyDeviceToHost));
     for (int i = 0; i < nn; ++i) sigma[i] = sg[i];
   }
@@ -975,6 +1023,12 @@ extern "C" int tnml_get_env(tnml_ctx *c, int side, int site, float *out, size_t 
   return TNML_OK;
 }
 
+extern "C" int tnml_set_narrow_path(tnml_ctx *c, int force_large) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  c->force_big = force_large != 0;
+  return TNML_OK;
+}
+
 extern "C" int tnml_set_svd_stop(tnml_ctx *c, double stop2) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   if (!(stop2 >= 1e-12 && stop2 <= 1e-2)) return fail(TNML_ERR_ARG, "svd stop threshold %g outside [1e-12, 1e-2]", stop2);
@@ -995,9 +1049,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
   if (c->last_bsize <= 0) return fail(TNML_ERR_STATE, "no step has run yet");
   HIP_TRY(hipSetDevice(c->device));
   const size_t Bs = c->last_bsize;
-  std::vector<double> hbuf(4 * Bs + 64 + 48);   // tensors, sigma, 5 scalars, 14 stamps
-  HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, (4 * Bs + 64 + 5) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + 64 + 5, c->dbg + 4 * c->bmax + 64 + 5, 35 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  std::vector<double> hbuf(4 * Bs + kDbgSigma + 48);   // tensors, sigma, 5 scalars, 14 stamps
+  HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, (4 * Bs + kDbgSigma + 5) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + kDbgSigma + 5, c->dbg + 4 * c->bmax + kDbgSigma + 5, 35 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   auto tensor_out = [&](size_t block) -> int {
     if (capacity < Bs) return fail(TNML_ERR_ARG, "capacity too small");
@@ -1026,7 +1080,7 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
       return TNML_OK;
     case TNML_DBG_L2:
       if (capacity < 40) return fail(TNML_ERR_ARG, "capacity too small");
-      memcpy(out, hbuf.data() + 4 * Bs + 64, 40 * sizeof(double));
+      memcpy(out, hbuf.data() + 4 * Bs + kDbgSigma, 40 * sizeof(double));
       if (n_out) *n_out = 40;
       return TNML_OK;
   }

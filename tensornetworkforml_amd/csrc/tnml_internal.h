@@ -14,8 +14,9 @@ constexpr int kD = 2;           // feature dimension the kernels are specialised
 constexpr int kTS = 32;         // samples per workgroup in the wide step kernel (v1)
 constexpr int kWideThreads = 1024; // 4 waves per SIMD: the v1 formulation is latency-bound
 constexpr int kNarrowThreads = 1024;
-constexpr int kMetricSlots = 4;
-constexpr double kSvdStop2Default = 1e-6;   // see jacobi_rot (kernels_narrow.hip) and tnml_set_svd_stop // per-slab tail: correct count, sum|y-fa|, non-finite count, pad
+constexpr int kMetricSlots = 4;    // per-slab tail: correct count, sum|y-fa|, non-finite count, pad
+constexpr int kDbgSigma = 128;     // capture block: 4 tensors, then this many singular values, then scalars
+constexpr double kSvdStop2Default = 1e-6;   // see jacobi_rot (jacobi_device.h) and tnml_set_svd_stop
 
 // A plain (label-free) core or the label core addressed in the sweep-relative frame.
 //   plain:  A(in, d, out)      = base[in*s_in + d*s_d + out*s_out]
@@ -104,6 +105,22 @@ void launch_wide(const WideParams &p, int nblk, hipStream_t st);
 void launch_f_only(const WideParams &p, int nblk, hipStream_t st);
 void launch_reduce(const float *slabs, int nblk, int slab_stride, int n, float *red, hipStream_t st);
 void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st);
+// Large-tensor path of the same step (kernels_big.hip): HBM scratch, n = min(rows, cols) <= 128.
+struct BigScratch {
+  float *Bf;          // [bmax]   merged tensor
+  double *T;          // [bmax]   Nh^T . B
+  double *part;       // [128][3] block-partial sums
+  double *gram;       // [128][128]
+  double2 *rotlog;    // [(kJacobiMaxSweeps * 127 + 2)][64] rotations (c, s) in application order
+  double *lam;        // [128]
+  int *info;          // rounds applied, sweeps, converged
+  double *VW;         // [(rows + cols)][n]  V, then W^T V
+  float *Cb;          // [rows][m]  new behind core, contiguous
+  double *T2;         // [rows][m]
+};
+constexpr int kBigMaxN = 128;
+size_t big_jacobi_lds_bytes(int n);
+void launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st);
 size_t narrow_lds_bytes(int h, int g, int s, int L, int m);
 void launch_norm_chain(const NormChainSite *sites_dev, int n_sites, const float *cores, double *env_base,
                        int Mmax, hipStream_t st);

@@ -67,9 +67,14 @@ def canon_to(d_arr, shape):
 gauge_signs, regauge = gu.gauge_signs, gu.regauge
 
 
-@pytest.mark.parametrize('name', gu.names('traj_'))
-def test_stepwise_vs_oracle_and_golden(name):
-    """Device and float64 oracle run the same sweeps side by side, one step per call; every step's
+BIG_PATH_CASES = ['traj_fixed_N16_script', 'traj_reference_N16_script', 'traj_fixed_L3', 'traj_fixed_L10',
+                  'traj_fixed_softmax_full_cross_ent_L21', 'traj_reference_sigmoid_MSE_L20']
+
+
+@pytest.mark.parametrize('name,large', [(n, False) for n in gu.names('traj_')] + [(n, True) for n in BIG_PATH_CASES])
+def test_stepwise_vs_oracle_and_golden(name, large):
+    """(`large`: the same through the large-tensor path.)
+    Device and float64 oracle run the same sweeps side by side, one step per call; every step's
     merged tensor, raw gradient, weight-decay term, updated tensor, singular values, f and metrics
     are compared.  The oracle itself is pinned to the reference by tests/test_oracle_golden.py; the
     golden f_new / accuracy are checked directly too."""
@@ -80,6 +85,7 @@ def test_stepwise_vs_oracle_and_golden(name):
     cores0 = gu.indexed(d, 'init_core', N)
     st = mo.MPSState(N, D, L, M, cores0, 0)
     ctx = make_ctx(N, D, L, M, cores0, 0, X, y)
+    ctx.set_narrow_path(large)       # True: the HBM-resident kernels (kernels_big.hip) instead of the in-LDS one
     ctx.debug_enable(True)
     y1h = mo.one_hot(y, L)
     k = 0
@@ -147,7 +153,9 @@ def test_stepwise_vs_oracle_and_golden(name):
 
 
 @pytest.mark.parametrize('policy,M,N,b,L', [('fixed', 20, 48, 300, 2), ('reference', 10, 40, 130, 2),
-                                            ('fixed', 12, 24, 77, 3)])
+                                            ('fixed', 12, 24, 77, 3),
+                                            # C5-shaped (10 labels, bond 40): merged tensor 80 x 800, the large-tensor path
+                                            ('fixed', 40, 10, 70, 10)])
 def test_full_sweeps_vs_oracle(policy, M, N, b, L):
     """Whole sweeps in one call (n_steps = N-1): ragged batch sizes (padding lanes), headline-like
     bond, both directions."""
