@@ -31,6 +31,8 @@ CONFIGS = {
     # name: (N, M, b_per_gpu, L)
     'c2': (784, 10, 1000, 2),
     'c3': (784, 20, 5000, 2),
+    'c4': (784, 20, 2500, 2),     # per-GPU share of batch 20000 over 8 GPUs (run with --gpus 8)
+    'c5': (784, 50, 5000, 10),    # ten labels, bond 50: the large-tensor path of the step (kernels_big.hip)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
@@ -157,6 +159,20 @@ def main():
         dt = float(t.item())
 
     sw_tot, n_svd, rounds_tot = ctx.svd_stats(reset=True)
+    # SURVEY.md 8.4 break-down: the environment build (forward) and the host -> device hand-over of one batch
+    # on their own, and the rate of the sweep alone
+    ctx.synchronize()
+    ctx.timer_start()
+    ctx.forward(want_f=False)
+    fwd_ms = ctx.timer_stop()
+    left_dir = ctx.l_pos == N - 1
+    ctx.sweep(left_dir, N - 1, True, hp['lr'], hp['weight_dec'], hp['L2_flag'], hp['act_fn'], hp['loss_fn'], hp['T'],
+              hp['trunc'], want_metrics=False, want_f=False)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.set_input(X, y)
+    ctx.synchronize()
+    h2d_ms = 1e3 * (time.perf_counter() - t0)
     # validity: one more pass handing back metrics and f; non-finite values raise inside the library
     met, f = one_pass(want=True)
     finite = bool(np.isfinite(f).all() and np.isfinite(met).all())
@@ -181,6 +197,9 @@ def main():
                                % (args.config, L, M, b, args.policy, hp['L2_flag'], N - 1),
                    'global_batch': b * world, 'sweep_steps_per_pass': N - 1, 'parallelism': 'dp%d' % world},
         'finite': finite,
+        'breakdown': {'forward_ms': fwd_ms, 'h2d_batch_ms': h2d_ms,
+                      'sweep_only_steps_per_s': (N - 1) / max(1e-3 * (1e3 * dt / args.steps - fwd_ms), 1e-9),
+                      'steps_per_s_incl_h2d': (N - 1) / (dt / args.steps + 1e-3 * h2d_ms)},
         'final_accuracy': float(met[-1, 0]),
         # the SVD is iterative: how much work the timed passes actually contained
         'jacobi': {'sweeps_per_svd': sw_tot / max(n_svd, 1), 'rounds_per_svd': rounds_tot / max(n_svd, 1),
