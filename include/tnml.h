@@ -142,6 +142,12 @@ int tnml_l2_term(tnml_ctx *ctx, const float *B_canon, int left_dir, float weight
 int tnml_svd_split(tnml_ctx *ctx, const float *mat, int rows, int cols, int m, float *US, float *SVh,
                    double *sigma);
 
+/* Network.forward's return value for a batch that is NOT made resident (the validation loop of
+ * Network.train, Network_class.py:339-346): X [b][N][D] -> f_out [L][b].  One chain towards the label
+ * site, no environment is stored; the training batch, its environments and f stay as they are.  Same
+ * l_pos restriction as tnml_forward. */
+int tnml_predict(tnml_ctx *ctx, const float *X, int b, float *f_out);
+
 /* Accuracy / speed of the in-kernel Jacobi SVD (no reference analogue: the reference calls LAPACK,
  * Network_class.py:887).  The iteration ends after a sweep in which every rotation had
  * g^2 <= stop2 * scale^2; the off-diagonals left behind are of relative size ~stop2.  Default 1e-6

@@ -329,6 +329,17 @@ class Network():
             self._r_entries = None
         return Tensor(elem=f.astype(np.float64), axes_names=['l', 'b'])
 
+    def predict(self, X):
+        """forward(X)'s return value without making X the resident batch: no environment list is
+        rebuilt, `TX` and the training batch stay as they are (the validation loop of `train`,
+        Network_class.py:339-346, only needs f).  Not in the reference."""
+        assert self.N == X.shape[1], "The 1 dimension of the input data must be the flattened number of pixels"
+        lp = self.l_pos
+        if lp != 0 and lp != self.N - 1:
+            raise Exception('### Error ###\n l =', lp, ' -> forward should not be called if l has an intermediate position')
+        ctx = self._sync_to_device(max(self._b, 1))
+        return Tensor(elem=ctx.predict(X).astype(np.float64), axes_names=['l', 'b'])
+
     # ------------------------------------------------------------------------------------------
     # training
     # ------------------------------------------------------------------------------------------
@@ -353,7 +364,7 @@ class Network():
             epoch_val_acc = np.zeros(len(val_loader))
             for i, data in enumerate(val_loader, 0):
                 x, y = _unpack_batch(data)
-                epoch_val_acc[i] = self.accuracy(x, y)
+                epoch_val_acc[i] = self.accuracy(x, y, self.predict(x))      # same f as forward(x), nothing rebuilt
             val_acc.append(epoch_val_acc.mean())
             print('\r' + "Epoch %d/%d - train accuracy : %.4f - val accuracy: %.4f"
                   % (epoch, n_epochs, epoch_train_acc.mean(), val_acc[-1]))

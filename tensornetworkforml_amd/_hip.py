@@ -26,7 +26,7 @@ SYMBOLS = [
     'tnml_set_f', 'tnml_get_f', 'tnml_sweep', 'tnml_activation', 'tnml_get_env', 'tnml_debug_enable',
     'tnml_get_step_debug', 'tnml_l_pos', 'tnml_batch', 'tnml_timer_start', 'tnml_timer_stop',
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
-    'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path',
+    'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict',
 ]
 
 
@@ -88,6 +88,7 @@ def lib():
         L.tnml_l2_term.argtypes = [vp, f32p, C.c_int, C.c_float, f64p, f64p, C.c_size_t]
         L.tnml_set_svd_stop.argtypes = [vp, C.c_double]
         L.tnml_set_narrow_path.argtypes = [vp, C.c_int]
+        L.tnml_predict.argtypes = [vp, f32p, C.c_int, f32p]
         L.tnml_svd_split.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f64p]
         _lib = L
     return _lib
@@ -203,6 +204,15 @@ class Context:
             return None
         f = np.empty((self.L, self.b), dtype=np.float32)
         _chk(lib().tnml_forward(self._h, _ptr(f, C.c_float)))
+        return f
+
+    def predict(self, X):
+        """f (L, b) for a batch that does not become resident (no environments are stored)."""
+        X = _f32(X)
+        assert X.ndim == 3 and X.shape[1] == self.N and X.shape[2] == self.D, \
+            "The 1 dimension of the input data must be the flattened number of pixels"
+        f = np.empty((self.L, X.shape[0]), dtype=np.float32)
+        _chk(lib().tnml_predict(self._h, _ptr(X, C.c_float), X.shape[0], _ptr(f, C.c_float)))
         return f
 
     def forward_logabsmax(self):

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kChainThreads) void env_chain_kernel(
       if (LOGMODE) {
         atomicMax(&sMax[sl], __float_as_uint(fabsf(v)));   // non-negative floats order like their bits
       } else if (cs.env_out_off >= 0) {
-        env_base[cs.env_out_off + (size_t)o * b_pad + s] = v;
+        if (env_base) env_base[cs.env_out_off + (size_t)o * b_pad + s] = v;   // nullptr: prediction only, nothing kept
       } else {
         f[(size_t)o * b_pad + s] = v;
       }

@@ -77,6 +77,8 @@ struct tnml_ctx {
   BigScratch big{};                          // HBM scratch of the large-tensor path, allocated on first use
   bool big_ready = false;
   bool force_big = false;                    // tnml_set_narrow_path
+  float *Xpred_stage = nullptr, *Xpred = nullptr, *fpred = nullptr;   // tnml_predict's own batch (the resident one is untouched)
+  int pred_cap = 0;
   int slab_stride = 0, nblk_cap = 0, metrics_cap = 0;
   double *dbg = nullptr;
   size_t dbg_elems = 0;
@@ -212,7 +214,7 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->comm) ncclCommDestroy(c->comm);
   void *ptrs[] = {c->X, c->Xstage, c->y, c->f, c->ftmp, c->ftmp2, c->Lenv, c->Renv, c->cores, c->lab[0], c->lab[1],
                   c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2,
-                  c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
+                  c->Xpred_stage, c->Xpred, c->fpred, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -407,12 +409,8 @@ static int copy_f_out(tnml_ctx *c, const float *src_dev, float *f_out) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-static int run_chain(tnml_ctx *c, bool logmode) {
-  if (!c->cores_set) return fail(TNML_ERR_STATE, "cores were never set");
-  if (!c->have_input) return fail(TNML_ERR_STATE, "no input batch: call tnml_set_input first");
-  if (c->l_pos != 0 && c->l_pos != c->N - 1)
-    return fail(TNML_ERR_STATE, "forward should not be called if l has an intermediate position (l_pos = %d)", c->l_pos);
-  HIP_TRY(hipSetDevice(c->device));
+// chain order and strides of every site for the environment chain that ends at the label site
+static int upload_chain_table(tnml_ctx *c) {
   const int N = c->N, D = c->D, L = c->L;
   std::vector<ChainSite> tab(N);
   const bool right_envs = (c->l_pos == 0);
@@ -437,6 +435,19 @@ static int run_chain(tnml_ctx *c, bool logmode) {
   }
   HIP_TRY(hipMemcpyAsync(c->tables, tab.data(), tab.size() * sizeof(ChainSite), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));   // tab is a stack object
+  return TNML_OK;
+}
+
+static int run_chain(tnml_ctx *c, bool logmode) {
+  if (!c->cores_set) return fail(TNML_ERR_STATE, "cores were never set");
+  if (!c->have_input) return fail(TNML_ERR_STATE, "no input batch: call tnml_set_input first");
+  if (c->l_pos != 0 && c->l_pos != c->N - 1)
+    return fail(TNML_ERR_STATE, "forward should not be called if l has an intermediate position (l_pos = %d)", c->l_pos);
+  HIP_TRY(hipSetDevice(c->device));
+  const int N = c->N, D = c->D, L = c->L;
+  const bool right_envs = (c->l_pos == 0);
+  int rc0 = upload_chain_table(c);
+  if (rc0) return rc0;
   if (c->profile) HIP_TRY(hipEventRecord(c->pev0, c->stream));
   launch_env_chain((const ChainSite *)c->tables, N, c->cores, c->lab[c->lab_cur], c->X,
                    right_envs ? c->Renv : c->Lenv, c->f, c->b, c->b_pad, L, c->Mmax,
@@ -463,6 +474,43 @@ extern "C" int tnml_forward(tnml_ctx *c, float *f_out) {
   int rc = run_chain(c, false);
   if (rc) return rc;
   if (f_out) return copy_f_out(c, c->f, f_out);
+  return TNML_OK;
+}
+
+extern "C" int tnml_predict(tnml_ctx *c, const float *X, int b, float *f_out) {
+  // Network.forward's output for a batch that is NOT made resident (validation, Network_class.py:339-346):
+  // one chain towards the label site, no environment is stored, the training batch and its environments
+  // stay as they are.
+  if (!c || !X || !f_out) return fail(TNML_ERR_ARG, "NULL argument");
+  if (b < 1) return fail(TNML_ERR_ARG, "empty batch");
+  if (!c->cores_set) return fail(TNML_ERR_STATE, "cores were never set");
+  if (c->l_pos != 0 && c->l_pos != c->N - 1)
+    return fail(TNML_ERR_STATE, "forward should not be called if l has an intermediate position (l_pos = %d)", c->l_pos);
+  HIP_TRY(hipSetDevice(c->device));
+  const int N = c->N, D = c->D, L = c->L;
+  const int bp = (b + 63) / 64 * 64;
+  if (bp > c->pred_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->Xpred_stage) { (void)hipFree(c->Xpred_stage); (void)hipFree(c->Xpred); (void)hipFree(c->fpred); }
+    c->Xpred_stage = c->Xpred = c->fpred = nullptr;
+    c->pred_cap = 0;
+    HIP_TRY(hipMalloc(&c->Xpred_stage, (size_t)bp * N * D * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->Xpred, (size_t)bp * N * D * sizeof(float)));
+    HIP_TRY(hipMalloc(&c->fpred, (size_t)bp * L * sizeof(float)));
+    HIP_TRY(hipMemset(c->Xpred, 0, (size_t)bp * N * D * sizeof(float)));
+    c->pred_cap = bp;
+  }
+  const int bpad = c->pred_cap;
+  HIP_TRY(hipMemcpyAsync(c->Xpred_stage, X, (size_t)b * N * D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  launch_transpose_input(c->Xpred_stage, c->Xpred, b, bpad, N, c->stream);
+  int rc = upload_chain_table(c);
+  if (rc) return rc;
+  launch_env_chain((const ChainSite *)c->tables, N, c->cores, c->lab[c->lab_cur], c->Xpred, nullptr, c->fpred, b, bpad, L,
+                   c->Mmax, nullptr, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy2DAsync(f_out, (size_t)b * sizeof(float), c->fpred, (size_t)bpad * sizeof(float), (size_t)b * sizeof(float),
+                           L, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return TNML_OK;
 }
 

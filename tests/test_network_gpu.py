@@ -291,3 +291,39 @@ def test_tensor_svd_argument_errors_match_reference():
         net.tensor_svd(np.zeros((4, 4)))
     with pytest.raises(ValueError):
         net.tensor_svd(Tensor(elem=np.zeros((2, 2, 2)), axes_names=['i', 'j', 'k']))
+
+
+def test_predict_equals_forward_and_leaves_the_resident_batch_alone():
+    d = gu.load('traj_fixed_N16_script')
+    N, L = int(d['N']), int(d['L'])
+    X, y = d['X'], d['y']
+    rng = np.random.default_rng(11)
+    Xv = np.stack([np.sin(rng.random((37, N))), np.cos(rng.random((37, N)))], -1)
+    lr, wd = float(d['lr']), float(d['wd'])
+
+    def run(with_predict):
+        net = net_from_golden(d)
+        out = []
+        for sw in range(2):
+            f = net.forward(X)
+            if with_predict:
+                fp = net.predict(Xv)                               # a validation batch in between
+                assert list(fp.axes_names) == ['l', 'b'] and fp.elem.shape == (L, 37)
+                out.append(fp.elem.copy())
+                assert len(net.TX) == N and net.TX[0].elem.shape[0] == len(y)   # TX still the training batch
+            f = net.sweep(X, y, f, lr, wd, left_dir=(net.l_pos == N - 1))
+            out.append(f.elem.copy())
+        return net, out
+
+    net_a, with_p = run(True)
+    net_b, without = run(False)
+    # the sweeps are bit-identical with and without the interleaved prediction
+    assert np.array_equal(with_p[1], without[0]) and np.array_equal(with_p[3], without[1])
+    # predict(X) == forward(X), at both label ends (same kernel, same arithmetic)
+    for net in (net_a,):
+        assert np.array_equal(net.predict(Xv).elem, net.forward(Xv).elem)
+    with quiet():
+        val_acc, _ = net_b.train([list(zip(X, y))], [list(zip(Xv, rng.integers(0, L, 37)))], lr, n_epochs=1, weight_dec=wd)
+    assert 0.0 <= val_acc[0] <= 1.0
+    with pytest.raises(AssertionError):
+        net_b.predict(Xv[:, :-1])
