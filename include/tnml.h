@@ -53,7 +53,7 @@ typedef enum {
 /* activation / loss / truncation selectors (Network_class.py:127-133, :894-945) */
 enum { TNML_ACT_LINEAR = 0, TNML_ACT_SIGMOID = 1, TNML_ACT_SOFTMAX = 2 };
 enum { TNML_LOSS_MSE = 0, TNML_LOSS_CROSS_ENTROPY = 1, TNML_LOSS_FULL_CROSS_ENT = 2 };
-enum { TNML_TRUNC_REFERENCE = 0, TNML_TRUNC_FIXED = 1 };
+enum { TNML_TRUNC_REFERENCE = 0, TNML_TRUNC_FIXED = 1, TNML_TRUNC_ADAPTIVE = 2 };
 enum { TNML_SIDE_LEFT = 0, TNML_SIDE_RIGHT = 1 };
 
 /* what tnml_get_step_debug can hand back about the most recent sweep step */
@@ -161,6 +161,12 @@ int tnml_set_svd_stop(tnml_ctx *ctx, double stop2);
  * force_large = 1 sends every step down the second path (tests, diagnostics); 0 restores the automatic
  * choice.  Environment variable TNML_NARROW=big does the same for a whole process. */
 int tnml_set_narrow_path(tnml_ctx *ctx, int force_large);
+
+/* TNML_TRUNC_ADAPTIVE (not reference behaviour): tensor_svd computes the cumulative share of the singular
+ * values and the first index where it exceeds `threshold` (Network_class.py:889-891, default argument
+ * 0.999) but never uses it.  Under this policy the kept rank is min(M, index + 1), decided on the device
+ * from the full spectrum; tnml_sweep then synchronises once per step to learn the new bond dimension. */
+int tnml_set_trunc_threshold(tnml_ctx *ctx, double threshold);
 
 /* Network.apply_act_func / compute_loss_derivate on the device-resident f (:767-835);
  * act_out, lossder_out [L][b], either may be NULL.  input_is_activated != 0: f already went

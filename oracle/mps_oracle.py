@@ -36,7 +36,7 @@ import numpy as np
 
 ACTS = ('linear', 'sigmoid', 'softmax')
 LOSSES = ('MSE', 'cross_entropy', 'full_cross_ent')
-TRUNCS = ('reference', 'fixed')
+TRUNCS = ('reference', 'fixed', 'adaptive')
 
 
 class MPSState:
@@ -229,7 +229,7 @@ def trunc_rank(policy, left_dir, p, N, ml, D, mr, L, M):
     else:
         rows, cols = D * ml * L, D * mr
     nS = min(rows, cols)
-    if policy == 'fixed':
+    if policy in ('fixed', 'adaptive'):        # adaptive: this is the cap, adaptive_rank() decides below it
         return min(M, nS), True
     first = (p == 0)
     last = (p == N - 2)
@@ -256,6 +256,13 @@ def matricize(B, left_dir):
     return np.transpose(B, (1, 0, 4, 2, 3)).reshape(D * ml * L, D * mr)
 
 
+def adaptive_rank(S, cap, threshold=0.999):
+    """NOT reference behaviour: the reference computes `index = argmax(cumsum(S)/S.sum() > threshold)`
+    (Network_class.py:889-891) and never uses it.  Policy 'adaptive' keeps min(cap, index + 1)."""
+    cum = np.cumsum(S) / S.sum()
+    return int(min(cap, int(np.argmax(cum > threshold)) + 1))
+
+
 def tensor_svd(Bmat, m):
     """Full SVD, keep m, split sqrt(S) on both factors (Network_class.py:887, 912-915)."""
     U, S, Vh = np.linalg.svd(Bmat, full_matrices=False)
@@ -265,7 +272,7 @@ def tensor_svd(Bmat, m):
 
 def sweep_step(state, f_prev, y1h, lr, weight_dec, L2_flag=True, left_dir=False,
                act_fn='linear', loss_fn='cross_entropy', T=0.1, trunc='reference',
-               record=None):
+               record=None, threshold=0.999):
     """One two-site optimisation step (Network_class.py:440-573 incl. update_B :577-763).
 
     Returns f_new (L, b): the output recomputed from the updated, UN-truncated B (:494-523).
@@ -341,6 +348,8 @@ def sweep_step(state, f_prev, y1h, lr, weight_dec, L2_flag=True, left_dir=False,
         raise ValueError("shapes not aligned: the reference's un-truncated SVD factor does not fit "
                          "(Network_class.py:914 / :949)")
     Bmat = matricize(B_new, left_dir)
+    if trunc == 'adaptive':
+        m = adaptive_rank(np.linalg.svd(Bmat, compute_uv=False), m, threshold)
     US, SVh, S = tensor_svd(Bmat, m)
     if not left_dir:
         s.cores[p] = np.ascontiguousarray(US.reshape(D, ml, m).transpose(1, 0, 2))

@@ -10,6 +10,9 @@ without the library or without a gfx950 device every compute method raises.
 
 Differences from the reference, all opt-in or unavoidable:
   * arithmetic is float32 on the device (float64 inside the merged-tensor update and the SVD);
+  * `trunc='adaptive'` (not reference behaviour) keeps min(M, index + 1) singular values, `index` being
+    the cumulative-share index the reference computes and never uses (Network_class.py:889-891,
+    `threshold=0.999`);
   * `trunc='reference'` (default) reproduces the reference's truncation rule, including its
     ValueError for L > 2 (Network_class.py:914); `trunc='fixed'` keeps m = min(M, len(S)) on both
     factors -- the only policy under which the bond dimension M survives the first sweep;
@@ -127,13 +130,14 @@ class Network():
     """
 
     def __init__(self, N, M, D=2, L=10, T=0.1, normalize=False, calibration_X=None, act_fn='linear',
-                 loss_fn='cross_entropy', check=False, trunc='reference', device=0, svd_stop=None):
+                 loss_fn='cross_entropy', check=False, trunc='reference', device=0, svd_stop=None, threshold=0.999):
         self.N, self.D, self.L, self.M, self.T = N, D, L, M, T
         assert act_fn in _ACTS, "Please select an activation function between 'linear', 'sigmoid', 'softmax'"
         assert loss_fn in _LOSSES, "Please select a loss function between 'MSE', 'cross_entropy', 'full_cross_ent'"
-        assert trunc in _hip.TRUNC, "trunc must be 'reference' or 'fixed'"
+        assert trunc in _hip.TRUNC, "trunc must be 'reference', 'fixed' or 'adaptive'"
         self.act_fn, self.loss_fn, self.trunc = act_fn, loss_fn, trunc
         self._device = device
+        self._threshold = threshold        # cumulative-share threshold of trunc='adaptive'
         self._svd_stop = svd_stop          # None: the library default (include/tnml.h, tnml_set_svd_stop)
         self._init_runtime()
         self._l_pos = 0
@@ -198,6 +202,8 @@ class Network():
             self._ctx = _hip.Context(self.N, self.D, self.L, self.M, max(int(b), 1), self._device)
             if getattr(self, '_svd_stop', None) is not None:
                 self._ctx.set_svd_stop(self._svd_stop)
+            if getattr(self, '_threshold', None) is not None:
+                self._ctx.set_trunc_threshold(self._threshold)
         return self._ctx
 
     def _collect_user_edits(self):
@@ -507,7 +513,8 @@ class Network():
         rows, cols = T.elem.shape
         nS = min(rows, cols)
         lp = self.l_pos
-        if self.trunc == 'fixed':
+        adaptive = self.trunc == 'adaptive'
+        if self.trunc in ('fixed', 'adaptive'):
             m = min(self.M, nS)
         else:
             interior = (1 < lp < self.N - 1) if left_dir else (0 < lp < self.N - 2)
@@ -516,7 +523,12 @@ class Network():
                 # np.eye(m, m) * S[:m] in the reference (:914 / :949)
                 raise ValueError("operands could not be broadcast together with shapes (%d,%d) (%d,) " % (m, m, nS))
         ctx = self._sync_to_device()
-        US, SVh, _ = ctx.svd_split(np.asarray(T.elem, dtype=np.float32), m)
+        US, SVh, sig = ctx.svd_split(np.asarray(T.elem, dtype=np.float32), m)
+        if adaptive:
+            # the index the reference computes and never uses (:889-891), here it decides the rank
+            thr = threshold if getattr(self, '_threshold', None) is None else self._threshold
+            m = min(m, int(np.argmax(np.cumsum(sig) / sig.sum() > thr)) + 1)
+            US, SVh = US[:, :m], SVh[:m]
         TU = Tensor(elem=US.astype(np.float64), axes_names=['i', 'right'])
         TSVh = Tensor(elem=SVh.astype(np.float64), axes_names=['left', 'j'])
         TU.aggregations['i'] = T.aggregations['i']

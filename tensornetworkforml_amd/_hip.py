@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('TNML_LIB', os.path.join(_HERE, 'libtnml_hip.so'))   #
 
 ACT = {'linear': 0, 'sigmoid': 1, 'softmax': 2}
 LOSS = {'MSE': 0, 'cross_entropy': 1, 'full_cross_ent': 2}
-TRUNC = {'reference': 0, 'fixed': 1}
+TRUNC = {'reference': 0, 'fixed': 1, 'adaptive': 2}
 SIDE_LEFT, SIDE_RIGHT = 0, 1
 DBG = {'B': 0, 'dB_raw': 1, 'B_new': 2, 'sigma': 3, 'scalars': 4, 'L2_grad': 5}
 
@@ -26,7 +26,7 @@ SYMBOLS = [
     'tnml_set_f', 'tnml_get_f', 'tnml_sweep', 'tnml_activation', 'tnml_get_env', 'tnml_debug_enable',
     'tnml_get_step_debug', 'tnml_l_pos', 'tnml_batch', 'tnml_timer_start', 'tnml_timer_stop',
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
-    'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict',
+    'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict', 'tnml_set_trunc_threshold',
 ]
 
 
@@ -89,6 +89,7 @@ def lib():
         L.tnml_set_svd_stop.argtypes = [vp, C.c_double]
         L.tnml_set_narrow_path.argtypes = [vp, C.c_int]
         L.tnml_predict.argtypes = [vp, f32p, C.c_int, f32p]
+        L.tnml_set_trunc_threshold.argtypes = [vp, C.c_double]
         L.tnml_svd_split.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f64p]
         _lib = L
     return _lib
@@ -304,6 +305,10 @@ class Context:
     def set_svd_stop(self, stop2):
         """Jacobi stopping threshold on g^2 / scale^2 (include/tnml.h); default 1e-6."""
         _chk(lib().tnml_set_svd_stop(self._h, float(stop2)))
+
+    def set_trunc_threshold(self, threshold):
+        """Cumulative-share threshold of trunc='adaptive' (default 0.999)."""
+        _chk(lib().tnml_set_trunc_threshold(self._h, float(threshold)))
 
     def set_narrow_path(self, force_large):
         """True: every step takes the large-tensor (HBM-resident) path; False: automatic."""

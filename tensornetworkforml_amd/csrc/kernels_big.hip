@@ -397,11 +397,11 @@ __global__ __launch_bounds__(64) void big_replay_kernel(const float *__restrict_
 
 // ---- eigenvalue order, the two new cores, metrics ---------------------------------------------------------------
 __global__ __launch_bounds__(1024) void big_finish_kernel(NarrowParams p, const double *__restrict__ lam, const double *__restrict__ VW,
-                                                         const int *__restrict__ info, double *__restrict__ ws, float *__restrict__ Cb) {
+                                                         const int *__restrict__ info, double *__restrict__ ws, float *__restrict__ Cb, int *__restrict__ m_dev) {
   __shared__ double sLam[128], sSq[2][128];
   __shared__ int sOrd[128];
   const int tid = threadIdx.x, NT = 1024;
-  const int D = kD, h = p.h, g = p.g, L = p.L, m = p.m, Bs = p.bsize;
+  const int D = kD, h = p.h, g = p.g, L = p.L, Bs = p.bsize;
   const int r = D * h, c = D * g * L;
   const bool short_rows = r <= c;
   const int n = short_rows ? r : c, len = short_rows ? c : r;
@@ -415,6 +415,30 @@ __global__ __launch_bounds__(1024) void big_finish_kernel(NarrowParams p, const 
     ws[4 * (size_t)Bs + rank] = sqrt(lj);
   }
   __syncthreads();
+  // adaptive truncation (see narrow_step_kernel)
+  __shared__ int sM;
+  int ob_s_h = p.ob_s_h, ob_s_d = p.ob_s_d, oa_s_d = p.oa_s_d, oa_s_g = p.oa_s_g;
+  if (tid == 0) {
+    int me = p.m;
+    if (p.trunc_thr > 0.0) {
+      double tot = 0.0;
+      for (int j = 0; j < n; ++j) tot += sqrt(sLam[sOrd[j]]);
+      double cum = 0.0;
+      int idx = 0;
+      bool found = false;
+      for (int j = 0; j < n && !found; ++j) {
+        cum += sqrt(sLam[sOrd[j]]);
+        if (cum / tot > p.trunc_thr) { idx = j; found = true; }
+      }
+      me = min(p.m, idx + 1);
+      if (p.m_out) *p.m_out = me;
+    }
+    sM = me;
+    m_dev[0] = me;
+  }
+  __syncthreads();
+  const int m = sM;
+  if (p.trunc_thr > 0.0) { if (!p.left_dir) { ob_s_h = D * m; ob_s_d = m; } else { oa_s_d = m * L; oa_s_g = D * m * L; } }
   const double lam_max = sLam[sOrd[0]];
   for (int sp = tid; sp < m; sp += NT) {
     const double l_ = sLam[sOrd[sp]];
@@ -429,10 +453,10 @@ __global__ __launch_bounds__(1024) void big_finish_kernel(NarrowParams p, const 
     const float v = (float)(VW[(size_t)kk * n + sOrd[sp]] * sSq[0][sp]);
     if (short_rows) {
       Cb[kk * m + sp] = v;
-      p.out_behind[(kk / D) * p.ob_s_h + (kk % D) * p.ob_s_d + sp * p.ob_s_m] = v;
+      p.out_behind[(kk / D) * ob_s_h + (kk % D) * ob_s_d + sp * p.ob_s_m] = v;
     } else {
       const int l = kk % L, q = kk / L;
-      p.out_ahead[sp * p.oa_s_m + (q / g) * p.oa_s_d + (q % g) * p.oa_s_g + l] = v;
+      p.out_ahead[sp * p.oa_s_m + (q / g) * oa_s_d + (q % g) * oa_s_g + l] = v;
     }
   }
   // long-side factor: (W^T V)[x][pos_j] sigma_j^(-1/2)
@@ -441,10 +465,10 @@ __global__ __launch_bounds__(1024) void big_finish_kernel(NarrowParams p, const 
     const float v = (float)(VW[(size_t)(n + x) * n + sOrd[sp]] * sSq[1][sp]);
     if (short_rows) {            // x = (dk1, g_, l)
       const int l = x % L, q = x / L;
-      p.out_ahead[sp * p.oa_s_m + (q / g) * p.oa_s_d + (q % g) * p.oa_s_g + l] = v;
+      p.out_ahead[sp * p.oa_s_m + (q / g) * oa_s_d + (q % g) * oa_s_g + l] = v;
     } else {                     // x = (h_, dk)
       Cb[x * m + sp] = v;
-      p.out_behind[(x / D) * p.ob_s_h + (x % D) * p.ob_s_d + sp * p.ob_s_m] = v;
+      p.out_behind[(x / D) * ob_s_h + (x % D) * ob_s_d + sp * p.ob_s_m] = v;
     }
   }
   if (tid == 0) {
@@ -462,8 +486,9 @@ __global__ __launch_bounds__(1024) void big_finish_kernel(NarrowParams p, const 
 }
 
 // ---- behind norm environment of the next step: Nh_new = Cb^T (Nh (x) 1_d) Cb -----------------------------------
-__global__ __launch_bounds__(kBT) void big_norm_T_kernel(NarrowParams p, const float *__restrict__ Cb, double *__restrict__ T2) {
-  const int D = kD, h = p.h, m = p.m, DM = D * m;
+__global__ __launch_bounds__(kBT) void big_norm_T_kernel(NarrowParams p, const float *__restrict__ Cb, double *__restrict__ T2,
+                                                        const int *__restrict__ m_dev) {
+  const int D = kD, h = p.h, m = m_dev[0], DM = D * m;
   for (int e = blockIdx.x * kBT + threadIdx.x; e < h * DM; e += gridDim.x * kBT) {
     const int j = e % DM, i = e / DM;
     double acc = 0.0;
@@ -472,8 +497,9 @@ __global__ __launch_bounds__(kBT) void big_norm_T_kernel(NarrowParams p, const f
     T2[e] = acc;
   }
 }
-__global__ __launch_bounds__(kBT) void big_norm_out_kernel(NarrowParams p, const float *__restrict__ Cb, const double *__restrict__ T2) {
-  const int D = kD, h = p.h, m = p.m;
+__global__ __launch_bounds__(kBT) void big_norm_out_kernel(NarrowParams p, const float *__restrict__ Cb, const double *__restrict__ T2,
+                                                          const int *__restrict__ m_dev) {
+  const int D = kD, h = p.h, m = m_dev[0];
   for (int e = blockIdx.x * kBT + threadIdx.x; e < m * m; e += gridDim.x * kBT) {
     const int j = e % m, i = e / m;
     double acc = 0.0;
@@ -514,11 +540,11 @@ void launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   a.counters = p.counters; a.status = p.status;
   hipLaunchKernelGGL(big_jacobi_kernel, dim3(1), dim3(1024), big_jacobi_lds_bytes(n), st, a);
   hipLaunchKernelGGL(big_replay_kernel, dim3(n + len), dim3(64), 0, st, p.Bnew, n, len, si, sx, s.rotlog, s.info, s.VW);
-  hipLaunchKernelGGL(big_finish_kernel, dim3(1), dim3(1024), 0, st, p, s.lam, s.VW, s.info, ws, s.Cb);
+  hipLaunchKernelGGL(big_finish_kernel, dim3(1), dim3(1024), 0, st, p, s.lam, s.VW, s.info, ws, s.Cb, s.info + 3);
   if (p.Nh_new) {
     const int nb2 = std::min((p.h * D * p.m + kBT - 1) / kBT, 256);
-    hipLaunchKernelGGL(big_norm_T_kernel, dim3(nb2), dim3(kBT), 0, st, p, s.Cb, s.T2);
-    hipLaunchKernelGGL(big_norm_out_kernel, dim3(std::min((p.m * p.m + kBT - 1) / kBT, 256)), dim3(kBT), 0, st, p, s.Cb, s.T2);
+    hipLaunchKernelGGL(big_norm_T_kernel, dim3(nb2), dim3(kBT), 0, st, p, s.Cb, s.T2, s.info + 3);
+    hipLaunchKernelGGL(big_norm_out_kernel, dim3(std::min((p.m * p.m + kBT - 1) / kBT, 256)), dim3(kBT), 0, st, p, s.Cb, s.T2, s.info + 3);
   }
 }
 

@@ -548,9 +548,31 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   __syncthreads();
 
   if (p.stamps && tid == 0) t_c2b = __builtin_amdgcn_s_memtime();
+  // ---- adaptive truncation (not reference behaviour: the reference computes this index and never uses it,
+  // Network_class.py:889-891): keep the fewest singular values whose cumulative share exceeds the threshold
+  int mk = m, ob_s_h = p.ob_s_h, ob_s_d = p.ob_s_d, oa_s_d = p.oa_s_d, oa_s_g = p.oa_s_g;
+  if (p.trunc_thr > 0.0) {
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int j = 0; j < n; ++j) tot += sqrt(k.dLam[k.sOrd[j]]);
+      double cum = 0.0;
+      int idx = 0;
+      bool found = false;
+      for (int j = 0; j < n && !found; ++j) {
+        cum += sqrt(k.dLam[k.sOrd[j]]);
+        if (cum / tot > p.trunc_thr) { idx = j; found = true; }      // np.argmax(cumsum(S) / S.sum() > threshold)
+      }
+      const int me = min(m, idx + 1);
+      k.sFlag[2] = me;
+      if (p.m_out) *p.m_out = me;
+    }
+    __syncthreads();
+    mk = k.sFlag[2];
+    if (!p.left_dir) { ob_s_h = D * mk; ob_s_d = mk; } else { oa_s_d = mk * L; oa_s_g = D * mk * L; }
+  }
   // ---- phase 9: the two new cores -----------------------------------------------------------------
   const double lam_max = k.dLam[k.sOrd[0]];
-  for (int sp = tid; sp < m; sp += NT) {                 // sigma^(+-1/2) once per kept column (lam = sigma^2)
+  for (int sp = tid; sp < mk; sp += NT) {                 // sigma^(+-1/2) once per kept column (lam = sigma^2)
     const double lam = k.dLam[k.sOrd[sp]];
     const bool ok = lam > 1e-300 && lam > 1e-30 * lam_max;
     const double sq = ok ? sqrt(sqrt(lam)) : 0.0;
@@ -560,36 +582,36 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   __syncthreads();
   // short-side factor: q_j * sigma_j^(1/2)   (rows kk over waves, kept columns over lanes: no divisions)
   for (int kk = tid >> 6; kk < n; kk += NT >> 6)
-   for (int sp = tid & 63; sp < m; sp += 64) {
+   for (int sp = tid & 63; sp < mk; sp += 64) {
     const int j = k.sOrd[sp];
     const float v = (float)(V[kk * ne + j] * k.dSq[sp]);
     if (short_rows) {                       // kk = row index i = h_*D + dk  -> behind core
-      k.sCb[kk * m + sp] = v;
-      p.out_behind[(kk / D) * p.ob_s_h + (kk % D) * p.ob_s_d + sp * p.ob_s_m] = v;
+      k.sCb[kk * mk + sp] = v;
+      p.out_behind[(kk / D) * ob_s_h + (kk % D) * ob_s_d + sp * p.ob_s_m] = v;
     } else {                                // kk = column index (dk1*g + g_)*L + l -> ahead core
       const int l = kk % L, q = kk / L;
-      p.out_ahead[sp * p.oa_s_m + (q / g) * p.oa_s_d + (q % g) * p.oa_s_g + l] = v;
+      p.out_ahead[sp * p.oa_s_m + (q / g) * oa_s_d + (q % g) * oa_s_g + l] = v;
     }
    }
   // long-side factor: (W q_j) / sigma_j^(1/2); columns s', inner index the short one
   if (short_rows) {
     // long index = ahead group x = (dk1, g_, l) = qq * L + l: the label is the batch, rows are qq = (dk1, g_)
-    small_gemm_f64(L, D * g, m, n,
+    small_gemm_f64(L, D * g, mk, n,
                    [&](int l, int qq, int kk) { return (double)k.fB[kk * c + qq * L + l]; },
                    [&](int l, int kk, int sp) { return V[kk * ne + k.sOrd[sp]]; },
                    [&](int l, int qq, int sp, double acc) {
                      const int dk1 = qq >= g ? 1 : 0;                     // D == 2
-                     p.out_ahead[sp * p.oa_s_m + dk1 * p.oa_s_d + (qq - dk1 * g) * p.oa_s_g + l] = (float)(acc * k.dSq[ne + sp]);
+                     p.out_ahead[sp * p.oa_s_m + dk1 * oa_s_d + (qq - dk1 * g) * oa_s_g + l] = (float)(acc * k.dSq[ne + sp]);
                    });
   } else {
     // long index = behind group x = (h_, dk) = h_ * D + dk: dk is the batch, rows are h_
-    small_gemm_f64(D, h, m, n,
+    small_gemm_f64(D, h, mk, n,
                    [&](int dk, int h_, int kk) { return (double)k.fBp[(h_ * D + dk) * (c + 1) + kk]; },
                    [&](int dk, int kk, int sp) { return V[kk * ne + k.sOrd[sp]]; },
                    [&](int dk, int h_, int sp, double acc) {
                      const float v = (float)(acc * k.dSq[ne + sp]);
-                     k.sCb[(h_ * D + dk) * m + sp] = v;
-                     p.out_behind[h_ * p.ob_s_h + dk * p.ob_s_d + sp * p.ob_s_m] = v;
+                     k.sCb[(h_ * D + dk) * mk + sp] = v;
+                     p.out_behind[h_ * ob_s_h + dk * ob_s_d + sp * p.ob_s_m] = v;
                    });
   }
   __syncthreads();
@@ -598,17 +620,17 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   // ---- phase 10: behind norm environment of the next step ------------------------------------------
   if (p.Nh_new) {
     // T2[h_, (d, s'')] = sum_h' Nh[h_, h'] Cb[h', (d, s'')]
-    const int DM = D * m;
+    const int DM = D * mk;
     small_gemm_f64(1, h, DM, h,
                    [&](int, int i, int kk) { return k.dNh[i * h + kk]; },
                    [&](int, int kk, int j) { return (double)k.sCb[kk * DM + j]; },
                    [&](int, int i, int j, double v) { k.dT2[i * DM + j] = v; });
     __syncthreads();
     // Nh_new[s', s''] = sum_{(h_, d)} Cb[(h_, d), s'] T2[(h_, d), s'']
-    small_gemm_f64(1, m, m, h * D,
-                   [&](int, int i, int kk) { return (double)k.sCb[kk * m + i]; },
-                   [&](int, int kk, int j) { return k.dT2[kk * m + j]; },
-                   [&](int, int i, int j, double v) { p.Nh_new[i * m + j] = v; });
+    small_gemm_f64(1, mk, mk, h * D,
+                   [&](int, int i, int kk) { return (double)k.sCb[kk * mk + i]; },
+                   [&](int, int kk, int j) { return k.dT2[kk * mk + j]; },
+                   [&](int, int i, int j, double v) { p.Nh_new[i * mk + j] = v; });
   }
 
   if (p.stamps && tid == 0) {

@@ -61,6 +61,7 @@ struct tnml_ctx {
   int last_bsize = 0, last_n = 0, last_h = 0, last_g = 0, last_left_dir = 0;
   bool debug = false, profile = false, stamps = false;
   double svd_stop2 = kSvdStop2Default;
+  double trunc_thr = 0.999;                  // adaptive truncation threshold (tensor_svd's default argument)
   double prof_ms[4] = {0, 0, 0, 0};
   long long prof_n[4] = {0, 0, 0, 0};
   // device buffers
@@ -113,7 +114,7 @@ extern "C" int tnml_trunc_rank(int policy, int left_dir, int p, int N, int ml, i
   const int rows = left_dir ? D * ml * L : D * ml;
   const int cols = left_dir ? D * mr : D * mr * L;
   const int nS = std::min(rows, cols);
-  if (policy == TNML_TRUNC_FIXED) return std::min(M, nS);
+  if (policy == TNML_TRUNC_FIXED || policy == TNML_TRUNC_ADAPTIVE) return std::min(M, nS);   // adaptive: the cap
   const bool first = (p == 0), last = (p == N - 2);
   if (!left_dir) {
     if (first) return rows == nS ? nS : TNML_ERR_SHAPE;   // only Vh cut, U stays rows x rows
@@ -194,8 +195,8 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipMalloc(&c->scal, 64 * sizeof(float)));
   c->dbg_elems = 4 * c->bmax + kDbgSigma + 48;   // 4 tensors, sigma[kDbgSigma], 5 scalars, stamps
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
-  HIP_TRY(hipMalloc(&c->status, sizeof(int)));
-  HIP_TRY(hipMemsetAsync(c->status, 0, sizeof(int), c->stream));
+  HIP_TRY(hipMalloc(&c->status, 2 * sizeof(int)));      // [0] status word, [1] kept rank of the last adaptive step
+  HIP_TRY(hipMemsetAsync(c->status, 0, 2 * sizeof(int), c->stream));
   HIP_TRY(hipMalloc(&c->counters, 4 * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(c->counters, 0, 4 * sizeof(unsigned long long), c->stream));
   c->tables_bytes = (size_t)N * std::max(sizeof(ChainSite), sizeof(NormChainSite));
@@ -702,7 +703,8 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
   if (!c->have_input || !c->have_labels) return fail(TNML_ERR_STATE, "a sweep needs inputs and labels (tnml_set_input)");
   if (n_steps < 1) return fail(TNML_ERR_ARG, "n_steps < 1");
   if (act_fn < 0 || act_fn > 2 || loss_fn < 0 || loss_fn > 2) return fail(TNML_ERR_ARG, "unknown activation / loss");
-  if (trunc_policy != TNML_TRUNC_REFERENCE && trunc_policy != TNML_TRUNC_FIXED) return fail(TNML_ERR_ARG, "unknown truncation policy");
+  if (trunc_policy != TNML_TRUNC_REFERENCE && trunc_policy != TNML_TRUNC_FIXED && trunc_policy != TNML_TRUNC_ADAPTIVE)
+    return fail(TNML_ERR_ARG, "unknown truncation policy");
   left_dir = left_dir ? 1 : 0;
   const int N = c->N, D = c->D, L = c->L;
   HIP_TRY(hipSetDevice(c->device));
@@ -831,6 +833,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     n.Bdirect = Bdirect_dev;
     n.svd_stop2 = c->svd_stop2;
     n.stop_after_update = mode == 1;
+    if (trunc_policy == TNML_TRUNC_ADAPTIVE && mode == 0) { n.trunc_thr = c->trunc_thr; n.left_dir = left_dir; n.m_out = c->status + 1; }
     if (mode == 1) { n.Bnew = c->Bscr2; n.Nh_new = nullptr; }
     n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + kDbgSigma + 5 : nullptr;
     n.status = c->status;
@@ -853,7 +856,13 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       return TNML_OK;
     }
     // ---- bookkeeping ---------------------------------------------------------------------------
-    c->bond[p] = m;
+    int m_kept = m;
+    if (trunc_policy == TNML_TRUNC_ADAPTIVE) {       // the kept rank is decided on the device: one sync per step
+      HIP_TRY(hipMemcpyAsync(&m_kept, c->status + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (m_kept < 1 || m_kept > m) return fail(TNML_ERR_NONFINITE, "adaptive truncation returned rank %d (cap %d)", m_kept, m);
+    }
+    c->bond[p] = m_kept;
     c->l_pos = sa;
     c->lab_cur ^= 1;
     c->prev_h = h; c->prev_g = g; c->prev_p = p; c->prev_left_dir = left_dir;
@@ -1068,6 +1077,13 @@ extern "C" int tnml_get_env(tnml_ctx *c, int side, int site, float *out, size_t 
   for (int s = 0; s < c->b; ++s)
     for (int a = 0; a < m; ++a) out[(size_t)s * m + a] = tmp[(size_t)a * c->b_pad + s];
   if (m_out) *m_out = m;
+  return TNML_OK;
+}
+
+extern "C" int tnml_set_trunc_threshold(tnml_ctx *c, double threshold) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  if (!(threshold > 0.0 && threshold < 1.0)) return fail(TNML_ERR_ARG, "threshold %g outside (0, 1)", threshold);
+  c->trunc_thr = threshold;
   return TNML_OK;
 }
 

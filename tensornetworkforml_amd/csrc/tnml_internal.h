@@ -86,6 +86,9 @@ struct NarrowParams {
   unsigned long long *counters;  // [0] += jacobi sweeps, [1] += SVDs, [2] += jacobi rounds (always on)
   const float *Bdirect;    // if set: the merged tensor (relative layout) is given, the two cores are not read
   int stop_after_update;   // 1: return after B_new (standalone update_B / compute_L2_reg; needs dbg)
+  double trunc_thr;        // > 0: adaptive truncation threshold on cumsum(S) / sum(S); m is then the cap
+  int left_dir;            // direction (only read when trunc_thr > 0: the output strides follow the kept rank)
+  int *m_out;              // device int receiving the kept rank (adaptive truncation), may be nullptr
   double svd_stop2;        // Jacobi stops after a sweep whose rotations all had g^2 / scale^2 <= svd_stop2 (tnml_set_svd_stop)
   int *status;             // device status word: bit0 non-finite, bit1 jacobi not converged
 };

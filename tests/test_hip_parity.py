@@ -298,3 +298,41 @@ def test_svd_accuracy_late_in_training(stop2, tol):
     assert worst_prod < tol
     assert worst_sig < tol
     ctx.close()
+
+
+@pytest.mark.parametrize('large', [False, True])
+def test_adaptive_truncation_vs_oracle(large):
+    """trunc='adaptive' (labelled non-reference: the reference computes the index and never uses it,
+    Network_class.py:889-891): the kept rank comes from the device's singular values; bond dimensions, f and
+    metrics follow the oracle's over two sweeps."""
+    N, M, b, L, D = 14, 12, 90, 2, 2
+    rng = np.random.default_rng(21)
+    p = rng.random((b, N)) * (rng.random((b, N)) > 0.6)
+    X = np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32)
+    y = rng.integers(0, L, b)
+    st = mo.MPSState(N, D, L, M, mo.random_cores(N, M, D, L, rng=rng, scale=M * 0.5 * 0.64 * D))
+    mo.calibrate(st, X.astype(np.float64))
+    cores32 = [c.astype(np.float32) for c in st.cores]
+    st = mo.MPSState(N, D, L, M, [c.astype(np.float64) for c in cores32])
+    ctx = make_ctx(N, D, L, M, cores32, 0, X, y)
+    ctx.set_narrow_path(large)
+    thr = 0.97
+    ctx.set_trunc_threshold(thr)
+    X64 = X.astype(np.float64)
+    bonds_seen = set()
+    for sw in range(2):
+        f_o = mo.forward(st, X64)
+        f_d = ctx.forward()
+        assert relerr(f_d, f_o) < 1e-3
+        left_dir = st.l_pos == N - 1
+        vh = [[], []]
+        f_o = mo.sweep(st, X64, y, f_o, 1e-2, 1e-3, L2_flag=True, left_dir=left_dir, var_hist=vh, act_fn='softmax',
+                       loss_fn='full_cross_ent', T=0.1, trunc='adaptive', threshold=thr)
+        met, f_d = ctx.sweep(left_dir, N - 1, True, 1e-2, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'adaptive')
+        _, bond_d, lp = ctx.get_cores()
+        assert list(bond_d) == list(st.bond), (list(bond_d), list(st.bond))
+        bonds_seen.update(int(v) for v in bond_d)
+        assert relerr(f_d, f_o) < 5e-3
+        assert np.abs(met[:, 0] - np.array(vh[0])).max() <= 2.0 / b + 1e-6
+    assert len(bonds_seen) > 2 and min(bonds_seen) < M      # the rank really adapts
+    ctx.close()

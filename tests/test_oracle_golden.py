@@ -134,3 +134,14 @@ def test_shipped_model():
     close(f, d['f'])
     assert mo.accuracy(f, d['y']) == float(d['accuracy']) == 1.0
     close(mo.apply_act_func(f, str(d['act_fn']), float(d['T'])), d['act'])
+
+
+def test_adaptive_rank_is_the_index_the_reference_computes():
+    """Network_class.py:889-891: index = argmax(cumsum(S)/S.sum() > threshold); policy 'adaptive' keeps
+    min(cap, index + 1) (not reference behaviour: the reference never uses the index)."""
+    S = np.array([5.0, 3.0, 1.0, 0.5, 0.25, 0.25])
+    cum = np.cumsum(S) / S.sum()
+    assert mo.adaptive_rank(S, 6, 0.85) == int(np.argmax(cum > 0.85)) + 1 == 3
+    assert mo.adaptive_rank(S, 2, 0.85) == 2                     # capped by M
+    assert mo.adaptive_rank(S, 6, 0.999999) == 1 + int(np.argmax(cum > 0.999999))
+    assert mo.trunc_rank('adaptive', False, 3, 10, 4, 2, 4, 2, 5) == (5, True)
