@@ -21,6 +21,7 @@
 // projection W Q Q^T whatever the accuracy of the small sigma_j.
 #include "tnml_internal.h"
 #include "jacobi_device.h"
+#include "small_gemm_device.h"
 
 namespace tnml {
 
@@ -38,62 +39,6 @@ __device__ inline void block_sum3(double &a, double &b, double &c, double *scrat
   a = 0; b = 0; c = 0;
   for (int w = 0; w < nw; ++w) { a += scratch[w]; b += scratch[16 + w]; c += scratch[32 + w]; }
   __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------
-// C[M x N] = A[M x K] . B[K x N] on the matrix cores, float64 (v_mfma_f64_16x16x4_f64), for operands
-// that live in LDS.  The 16x16 output tiles are dealt round-robin to the waves of the workgroup;
-// loadA(i, k) / loadB(k, j) / store(i, j, value) are inlined index maps, called with in-range
-// indices only (out-of-range rows, columns and k are fed as zeros).
-// Lane maps (cdna_hip_programming.md section 3): A[row = lane & 15][k = lane >> 4],
-// B[k = lane >> 4][col = lane & 15], C/D col = lane & 15, row = (lane >> 4) + 4 * reg.
-// ------------------------------------------------------------------------------------------
-typedef double dvec4 __attribute__((ext_vector_type(4)));
-
-template <class FA, class FB, class FS>
-__device__ inline void small_gemm_f64(int nbatch, int M, int N, int K, FA loadA, FB loadB, FS store) {
-  // C_b[M x N] = A_b[M x K] . B_b[K x N] for b < nbatch; loadA(b, i, k), loadB(b, k, j),
-  // store(b, i, j, value) must be LINEAR index maps (no run-time divisions: they are evaluated per
-  // element); a composite row index such as (site index, label) is expressed through the batch.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int tn = (N + 15) >> 4, tm = (M + 15) >> 4, per = tm * tn, ntiles = nbatch * per;
-  const int r = lane & 15, q = lane >> 4;
-  for (int t = wave; t < ntiles; t += nw) {
-    const int bt = t / per, tt = t - bt * per;
-    const int ti = tt / tn;
-    const int i0 = ti << 4, j0 = (tt - ti * tn) << 4;
-    const bool va = i0 + r < M, vb = j0 + r < N;
-    const int ia = va ? i0 + r : M - 1, jb = vb ? j0 + r : N - 1;
-    // four k-steps of operands are fetched before the first MFMA of the group, two accumulators
-    // break the MFMA -> MFMA dependency
-    dvec4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-      double a[4], b[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kk = k0 + 4 * u + q;
-        const bool vk = kk < K;
-        const int kc = vk ? kk : K - 1;
-        a[u] = loadA(bt, ia, kc);
-        b[u] = loadB(bt, kc, jb);
-        a[u] = (va && vk) ? a[u] : 0.0;
-        b[u] = (vb && vk) ? b[u] : 0.0;
-      }
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
-      if (k0 + 8 < K) {                                    // wave-uniform
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
-      }
-    }
-    const dvec4 acc = acc0 + acc1;
-    const int j = j0 + r;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int i = i0 + q + 4 * reg;
-      if (i < M && j < N) store(bt, i, j, acc[reg]);
-    }
-  }
 }
 
 struct NarrowCarve {
@@ -139,11 +84,68 @@ size_t narrow_lds_bytes(int h, int g, int s, int L, int m) {
   return narrow_carve(nullptr, h, g, s, L, m).bytes + 16;
 }
 
+// ------------------------------------------------------------------------------------------
+// Helper workgroups of a fused launch (blockIdx.x >= 1).  They never wait for anybody, so the launch
+// cannot deadlock whatever the residency; workgroup 0 waits for their arrival counter.
+//   blocks 1 .. nred          : deterministic sum of the gradient slabs, 64 elements each (the arithmetic of
+//                               reduce_slabs_kernel, kernels_wide.hip)
+//   blocks nred+1 .. nred+D*D : slice (dk, dk1) of the merged tensor and of Ln.B.Rn -- both factorise over the
+//                               two feature indices, so the four slices are independent
+// ------------------------------------------------------------------------------------------
+__device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char *smem_raw) {
+  const int tid = threadIdx.x, NT = kNarrowThreads;
+  const int h = p.h, g = p.g, s = p.s, L = p.L, Bs = p.bsize;
+  const int blk = blockIdx.x - 1;
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  if (blk < p.nred) {
+    float *part = (float *)smem_raw;                       // [16][64]
+    const int el = tid & 63, chunk = tid >> 6;
+    const int e = blk * 64 + el, n = Bs + kMetricSlots;
+    const int per = (p.nslabs + 15) / 16;
+    const int k0 = chunk * per, k1 = min(p.nslabs, k0 + per);
+    float a0 = 0.f, a1 = 0.f;
+    if (e < n) {
+      int kk = k0;
+      for (; kk + 2 <= k1; kk += 2) {
+        a0 += p.slabs[(size_t)kk * p.slab_stride + e];
+        a1 += p.slabs[(size_t)(kk + 1) * p.slab_stride + e];
+      }
+      if (kk < k1) a0 += p.slabs[(size_t)kk * p.slab_stride + e];
+    }
+    part[chunk * 64 + el] = a0 + a1;
+    __syncthreads();
+    if (chunk == 0 && e < n) {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) t += part[c * 64 + el];
+      p.red_out[e] = t;
+    }
+  } else {
+    PrepParams q{};
+    q.lab = p.lab; q.pl = p.pl; q.Nh = p.Nh; q.Ng = p.Ng; q.h = h; q.g = g; q.s = s; q.L = L; q.l2_flag = p.l2_flag;
+    q.prepB = p.prepB; q.prepG = p.prepG;
+    prep_slice_block(q, blk - p.nred, smem_raw);
+  }
+  __syncthreads();                      // every wave's stores are ordered before thread 0's agent-scope release below
+  if (tid == 0) {
+    if (p.stamps && p.counters) {      // diagnostic: first start and last finish of either helper role, 100 MHz ticks
+      atomicMin(p.counters + (blk < p.nred ? 4 : 5), t_start);
+      atomicMax(p.counters + (blk < p.nred ? 6 : 7), __builtin_amdgcn_s_memrealtime());
+    }
+    __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (p.fused && blockIdx.x > 0) { narrow_helper_block(p, smem_raw); return; }
   const NarrowCarve k = narrow_carve(smem_raw, p.h, p.g, p.s, p.L, p.m);
   const int tid = threadIdx.x, NT = kNarrowThreads;
   const int D = kD, h = p.h, g = p.g, s = p.s, L = p.L, m = p.m, Bs = p.bsize;
+  // reduced gradient + metric tail: written by other workgroups of THIS launch when fused -> coherent loads
+  auto ldred = [&](int e) -> float {
+    return p.fused ? __hip_atomic_load(p.red + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.red[e];
+  };
   const int r = D * h, c = D * g * L;
   const bool short_rows = (r <= c);
   const int n = short_rows ? r : c, ne = n + (n & 1), len = short_rows ? c : r;
@@ -153,7 +155,40 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 #define TNML_STAMP(i) if (p.stamps && tid == 0) t_p[i] = __builtin_amdgcn_s_memtime()
   if (p.stamps && tid == 0) { t_c0 = __builtin_amdgcn_s_memtime(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
   // ---- phase 0: stage the two cores and the norm environments ---------------------------------
-  if (!p.Bdirect) {
+  if (p.fused) {
+    // B and Ln.B.Rn come from the slice workgroups of the preceding wide launch (prep_ready: plain loads, issued
+    // before the wait) or of this launch; red always from the reduce workgroups of this launch
+    if (p.prep_ready)
+      for (int e = tid; e < Bs; e += NT) {
+        k.fB[e] = p.prepB[e];
+        if (p.l2_flag) k.dG[e] = p.prepG[e];
+      }
+    if (tid == 0) {
+      const unsigned want = gridDim.x - 1;
+      int spins = 0;
+      while (__hip_atomic_load(p.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1 << 22)) {
+        __builtin_amdgcn_s_sleep(8);
+        ++spins;
+      }
+      if (spins >= (1 << 22)) atomicOr(p.status, 4);
+      __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p.stamps && p.counters) {      // ticks of the 100 MHz counter relative to this workgroup's start
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        p.stamps[28] = (double)(now - t_r0);                                   // wait over
+        p.stamps[29] = (double)(long long)(p.counters[4] - t_r0);              // first reduce helper started
+        p.stamps[30] = (double)(long long)(p.counters[6] - t_r0);              // last reduce helper done
+        p.stamps[31] = (double)(long long)(p.counters[5] - t_r0);              // first slice helper started
+        p.stamps[32] = (double)(long long)(p.counters[7] - t_r0);              // last slice helper done
+        p.stamps[33] = (double)spins;
+        p.counters[4] = ~0ull; p.counters[5] = ~0ull; p.counters[6] = 0ull; p.counters[7] = 0ull;
+      }
+    }
+    __syncthreads();
+    if (!p.prep_ready) for (int e = tid; e < Bs; e += NT) {
+      k.fB[e] = __hip_atomic_load(p.prepB + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p.l2_flag) k.dG[e] = __hip_atomic_load(p.prepG + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (!p.Bdirect) {
     for (int e = tid; e < h * D * s * L; e += NT) {
       const int l = e % L, q = e / L;
       const int s_ = q % s, q2 = q / s;
@@ -175,7 +210,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   TNML_STAMP(0);
   // ---- phase 1: B[h,dk,dk1,g,l] = sum_s lab(h,dk,s,l) * pl(s,dk1,g) ---------------------------
   const int RW = D * D * g * L;  // elements per behind-bond index
-  if (!p.Bdirect) {   // rows i = (h_, dk, l), columns j = (dk1, g_), inner index the shared bond
+  if (!p.Bdirect && !p.fused) {   // rows i = (h_, dk, l), columns j = (dk1, g_), inner index the shared bond
     const int QW = D * g;
     small_gemm_f64(L, h * D, QW, s,
                    [&](int l, int i, int kk) { return (double)k.sLab[(i * s + kk) * L + l]; },
@@ -186,7 +221,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 
   TNML_STAMP(1);
   // ---- phases 2-3: weight decay term ------------------------------------------------------------
-  if (p.l2_flag) {
+  if (p.l2_flag && !p.fused) {
     // T = Nh^T . B over the behind bond:  T[e_, rest] = sum_a Nh[a, e_] B[a, rest]
     small_gemm_f64(1, h, RW, h,
                    [&](int, int i, int kk) { return k.dNh[kk * h + i]; },
@@ -204,7 +239,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   double sumB = 0.0, sumD = 0.0, l2 = 0.0;
   for (int e = tid; e < Bs; e += NT) {
     const double bv = (double)k.fB[e];
-    const double raw = (double)p.red[e];
+    const double raw = (double)ldred(e);
     double wdterm;
     if (p.l2_flag) {
       const double gv = k.dG[e];
@@ -250,10 +285,10 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   __syncthreads();   // dT/dG are dead from here on; Z aliases them
   if (p.stop_after_update) {                       // standalone update_B / compute_L2_reg
     if (tid == 0 && p.metrics) {
-      const double cnt = (double)p.red[Bs + 3];
+      const double cnt = (double)ldred(Bs + 3);
       const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
-      p.metrics[0] = (float)((double)p.red[Bs] * inv);
-      p.metrics[1] = (float)((double)p.red[Bs + 1] * inv / (double)L);
+      p.metrics[0] = (float)((double)ldred(Bs) * inv);
+      p.metrics[1] = (float)((double)ldred(Bs + 1) * inv / (double)L);
     }
     return;
   }
@@ -646,11 +681,11 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 
   // ---- phase 11: metrics of this step (var_hist, Network_class.py:739-750) --------------------------
   if (tid == 0 && p.metrics) {
-    const double cnt = (double)p.red[Bs + 3];
+    const double cnt = (double)ldred(Bs + 3);
     const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
-    p.metrics[0] = (float)((double)p.red[Bs] * inv);
-    p.metrics[1] = (float)((double)p.red[Bs + 1] * inv / (double)L);
-    if (p.red[Bs + 2] != 0.f) atomicOr(p.status, 1);
+    p.metrics[0] = (float)((double)ldred(Bs) * inv);
+    p.metrics[1] = (float)((double)ldred(Bs + 1) * inv / (double)L);
+    if (ldred(Bs + 2) != 0.f) atomicOr(p.status, 1);
   }
 #ifdef TNML_EXP_ROUND_TIMING
   // timing experiment (tools/build_exp.sh): ne-1 rounds each with parts of the round switched off, on the
@@ -671,7 +706,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 }
 
 void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st) {
-  hipLaunchKernelGGL(narrow_step_kernel, dim3(1), dim3(kNarrowThreads), lds_bytes, st, p);
+  hipLaunchKernelGGL(narrow_step_kernel, dim3(p.fused ? 1 + p.nred + (p.prep_ready ? 0 : kD * kD) : 1), dim3(kNarrowThreads), lds_bytes, st, p);
 }
 
 // ------------------------------------------------------------------------------------------

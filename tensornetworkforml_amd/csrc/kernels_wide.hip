@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "tnml_internal.h"
+#include "small_gemm_device.h"
 
 namespace tnml {
 
@@ -467,8 +468,14 @@ __host__ __device__ inline WideMfmaSmem wide_mfma_carve(float *base, WideMfmaDim
   return w;
 }
 
-__global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_kernel(WideParams p) {
+__global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_kernel(WideParams p, PrepParams prep, int nblk_samples) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x >= nblk_samples) {
+    // batch-independent side job on CUs the sample tiles leave idle: slice (dk, dk1) of the merged tensor of THIS
+    // step and of its L2 term, for the narrow kernel that follows (small_gemm_device.h)
+    prep_slice_block(prep, blockIdx.x - nblk_samples, (unsigned char *)smem);
+    return;
+  }
   WideMfmaDims dm = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
   const WideMfmaSmem w = wide_mfma_carve(smem, dm, p.L, p.h, p.hp, p.gp, p.g);
   const int tid = threadIdx.x, NT = kMfmaThreads;
@@ -694,13 +701,19 @@ static bool wide_use_mfma() {
   return v != 0;
 }
 
-void launch_wide(const WideParams &p, int nblk, hipStream_t st) {
+bool launch_wide(const WideParams &p, int nblk, const PrepParams *prep, hipStream_t st) {
   if (wide_use_mfma()) {
     WideMfmaDims dm = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
-    const size_t lds = wide_mfma_carve(nullptr, dm, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
+    size_t lds = wide_mfma_carve(nullptr, dm, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
     if (lds <= 160 * 1024) {
-      hipLaunchKernelGGL(wide_step_mfma_kernel, dim3(nblk), dim3(kMfmaThreads), lds, st, p);
-      return;
+      PrepParams q{};
+      int extra = 0;
+      if (prep) {
+        const size_t need = prep_slice_lds_bytes(prep->h, prep->g, prep->s, prep->L);
+        if (need <= 160 * 1024) { q = *prep; extra = kD * kD; if (need > lds) lds = need; }
+      }
+      hipLaunchKernelGGL(wide_step_mfma_kernel, dim3(nblk + extra), dim3(kMfmaThreads), lds, st, p, q, nblk);
+      return extra > 0;
     }
   }
   const int hmax = p.h > p.hp ? p.h : p.hp;
@@ -708,6 +721,7 @@ void launch_wide(const WideParams &p, int nblk, hipStream_t st) {
   const int core_elems = p.do_ext ? p.ext_core.n_in * kD * p.ext_core.n_out : 0;
   hipLaunchKernelGGL(wide_step_kernel, dim3(nblk), dim3(kWideThreads), wide_lds_bytes(hmax, gmax, p.L, core_elems),
                      st, p, hmax, gmax, core_elems);
+  return false;
 }
 
 void launch_f_only(const WideParams &p, int nblk, hipStream_t st) {

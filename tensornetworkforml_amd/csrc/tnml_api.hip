@@ -78,6 +78,9 @@ struct tnml_ctx {
   BigScratch big{};                          // HBM scratch of the large-tensor path, allocated on first use
   bool big_ready = false;
   bool force_big = false;                    // tnml_set_narrow_path
+  float *prepB = nullptr;                    // fused narrow launch: merged tensor / L2 term from the helper workgroups
+  double *prepG = nullptr;
+  unsigned *sync = nullptr;
   float *Xpred_stage = nullptr, *Xpred = nullptr, *fpred = nullptr;   // tnml_predict's own batch (the resident one is untouched)
   int pred_cap = 0;
   int slab_stride = 0, nblk_cap = 0, metrics_cap = 0;
@@ -188,6 +191,10 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipMalloc(&c->Rn, (size_t)N * Mmax * Mmax * sizeof(double)));
   HIP_TRY(hipMalloc(&c->Bnew, c->bmax * sizeof(float)));
   HIP_TRY(hipMalloc(&c->Bscr, c->bmax * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->prepB, c->bmax * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->prepG, c->bmax * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->sync, sizeof(unsigned)));
+  HIP_TRY(hipMemset(c->sync, 0, sizeof(unsigned)));
   HIP_TRY(hipMalloc(&c->Bscr2, c->bmax * sizeof(float)));
   HIP_TRY(hipMalloc(&c->red, (size_t)c->slab_stride * sizeof(float)));
   c->metrics_cap = N;
@@ -197,8 +204,8 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
   HIP_TRY(hipMalloc(&c->status, 2 * sizeof(int)));      // [0] status word, [1] kept rank of the last adaptive step
   HIP_TRY(hipMemsetAsync(c->status, 0, 2 * sizeof(int), c->stream));
-  HIP_TRY(hipMalloc(&c->counters, 4 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemsetAsync(c->counters, 0, 4 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMalloc(&c->counters, 8 * sizeof(unsigned long long)));     // [0..2] Jacobi statistics, [4..7] fused-launch timing diagnostics
+  HIP_TRY(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
   c->tables_bytes = (size_t)N * std::max(sizeof(ChainSite), sizeof(NormChainSite));
   HIP_TRY(hipMalloc(&c->tables, c->tables_bytes));
   int rc = alloc_batch_buffers(c, b_capacity);
@@ -215,7 +222,7 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->comm) ncclCommDestroy(c->comm);
   void *ptrs[] = {c->X, c->Xstage, c->y, c->f, c->ftmp, c->ftmp2, c->Lenv, c->Renv, c->cores, c->lab[0], c->lab[1],
                   c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2,
-                  c->Xpred_stage, c->Xpred, c->fpred, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
+                  c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -754,6 +761,53 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     const int npath = narrow_path(c, h, g, s, L, m);
     if (npath < 0) return npath;
 
+    // ---- parameters of the narrow kernel (built first: the wide launch carries its slice workgroups) ---------
+    // single GPU + in-LDS path: the slab reduction rides in the narrow launch as helper workgroups (no separate
+    // reduce kernel, no boundary) and the merge / L2 products ride in the wide launch (or, with the plain-FMA wide
+    // kernel, in the narrow launch as well); TNML_NARROW_FUSED=0 turns all of that off
+    static const bool fuse_ok = !(getenv("TNML_NARROW_FUSED") && atoi(getenv("TNML_NARROW_FUSED")) == 0);
+    const bool fused = fuse_ok && !c->comm && npath == 0 && mode == 0 && !Bdirect_dev;
+    NarrowParams n{};
+    n.L = L; n.D = D; n.h = h; n.g = g; n.s = s; n.m = m; n.bsize = (int)bsize;
+    n.l2_flag = l2_flag ? 1 : 0; n.lr = lr; n.wd = weight_dec;
+    n.red = c->red;
+    n.lab.base = c->lab[c->lab_cur]; n.lab.n_in = h; n.lab.n_out = s;
+    n.pl.base = c->core_slot(sa); n.pl.n_in = s; n.pl.n_out = g;
+    if (!left_dir) {
+      n.lab.s_in = D * s * L; n.lab.s_d = s * L; n.lab.s_out = L;
+      n.pl.s_in = D * g; n.pl.s_d = g; n.pl.s_out = 1;
+      n.ob_s_h = D * m; n.ob_s_d = m; n.ob_s_m = 1;
+      n.oa_s_m = D * g * L; n.oa_s_d = g * L; n.oa_s_g = L;
+    } else {
+      n.lab.s_in = L; n.lab.s_d = h * L; n.lab.s_out = D * h * L;
+      n.pl.s_in = 1; n.pl.s_d = s; n.pl.s_out = D * s;
+      n.ob_s_h = 1; n.ob_s_d = h; n.ob_s_m = D * h;
+      n.oa_s_m = L; n.oa_s_d = m * L; n.oa_s_g = D * m * L;
+    }
+    {
+      const int bs_ = left_dir ? p + 2 : p - 1;     // norm env behind: sites t < k
+      const int as_ = left_dir ? p - 1 : p + 2;     // norm env ahead:  sites t > k+1
+      n.Nh = (l2_flag && bs_ >= 0 && bs_ <= N - 1) ? c->norm_slot(nbeh, bs_) : nullptr;
+      n.Ng = (l2_flag && as_ >= 0 && as_ <= N - 1) ? c->norm_slot(nahe, as_) : nullptr;
+      n.Nh_new = l2_flag ? c->norm_slot(nbeh, sb) : nullptr;
+    }
+    n.Bnew = c->Bnew;
+    n.out_behind = c->core_slot(sb);
+    n.out_ahead = c->lab[c->lab_cur ^ 1];
+    n.metrics = c->metrics + 2 * (size_t)step;
+    n.dbg = (c->debug || mode == 1) ? c->dbg : nullptr;
+    n.Bdirect = Bdirect_dev;
+    n.svd_stop2 = c->svd_stop2;
+    n.stop_after_update = mode == 1;
+    if (fused) {
+      n.fused = 1; n.slabs = c->slabs; n.nslabs = nblk; n.slab_stride = c->slab_stride;
+      n.nred = ((int)bsize + kMetricSlots + 63) / 64; n.red_out = c->red; n.prepB = c->prepB; n.prepG = c->prepG; n.sync = c->sync;
+    }
+    if (trunc_policy == TNML_TRUNC_ADAPTIVE && mode == 0) { n.trunc_thr = c->trunc_thr; n.left_dir = left_dir; n.m_out = c->status + 1; }
+    if (mode == 1) { n.Bnew = c->Bscr2; n.Nh_new = nullptr; }
+    n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + kDbgSigma + 5 : nullptr;
+    n.status = c->status;
+    n.counters = c->counters;
     // ---- wide kernel -----------------------------------------------------------------------
     WideParams w{};
     w.b = c->b; w.b_pad = c->b_pad; w.L = L;
@@ -792,52 +846,19 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       w.Gcur = (gs >= 0 && gs <= N - 1) ? c->env_slot(ahe, gs) : nullptr;
     }
     w.stamps = c->stamps ? c->dbg + 4 * c->bmax + kDbgSigma + 5 + 17 : nullptr;
+    PrepParams prep{};
+    prep.lab = n.lab; prep.pl = n.pl; prep.Nh = n.Nh; prep.Ng = n.Ng; prep.h = h; prep.g = g; prep.s = s; prep.L = L;
+    prep.l2_flag = n.l2_flag; prep.prepB = c->prepB; prep.prepG = c->prepG;
     prof_begin(c);
-    launch_wide(w, nblk, c->stream);
+    n.prep_ready = launch_wide(w, nblk, fused ? &prep : nullptr, c->stream) ? 1 : 0;
     prof_end(c, 1);
     // ---- reduce (+ all-reduce over the batch shards) -----------------------------------------
-    prof_begin(c);
-    launch_reduce(c->slabs, nblk, c->slab_stride, (int)bsize + kMetricSlots, c->red, c->stream);
-    prof_end(c, 2);
+    if (!fused) {
+      prof_begin(c);
+      launch_reduce(c->slabs, nblk, c->slab_stride, (int)bsize + kMetricSlots, c->red, c->stream);
+      prof_end(c, 2);
+    }
     if (c->comm) NCCL_TRY(ncclAllReduce(c->red, c->red, bsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
-    // ---- narrow kernel -----------------------------------------------------------------------
-    NarrowParams n{};
-    n.L = L; n.D = D; n.h = h; n.g = g; n.s = s; n.m = m; n.bsize = (int)bsize;
-    n.l2_flag = l2_flag ? 1 : 0; n.lr = lr; n.wd = weight_dec;
-    n.red = c->red;
-    n.lab.base = c->lab[c->lab_cur]; n.lab.n_in = h; n.lab.n_out = s;
-    n.pl.base = c->core_slot(sa); n.pl.n_in = s; n.pl.n_out = g;
-    if (!left_dir) {
-      n.lab.s_in = D * s * L; n.lab.s_d = s * L; n.lab.s_out = L;
-      n.pl.s_in = D * g; n.pl.s_d = g; n.pl.s_out = 1;
-      n.ob_s_h = D * m; n.ob_s_d = m; n.ob_s_m = 1;
-      n.oa_s_m = D * g * L; n.oa_s_d = g * L; n.oa_s_g = L;
-    } else {
-      n.lab.s_in = L; n.lab.s_d = h * L; n.lab.s_out = D * h * L;
-      n.pl.s_in = 1; n.pl.s_d = s; n.pl.s_out = D * s;
-      n.ob_s_h = 1; n.ob_s_d = h; n.ob_s_m = D * h;
-      n.oa_s_m = L; n.oa_s_d = m * L; n.oa_s_g = D * m * L;
-    }
-    {
-      const int bs_ = left_dir ? p + 2 : p - 1;     // norm env behind: sites t < k
-      const int as_ = left_dir ? p - 1 : p + 2;     // norm env ahead:  sites t > k+1
-      n.Nh = (l2_flag && bs_ >= 0 && bs_ <= N - 1) ? c->norm_slot(nbeh, bs_) : nullptr;
-      n.Ng = (l2_flag && as_ >= 0 && as_ <= N - 1) ? c->norm_slot(nahe, as_) : nullptr;
-      n.Nh_new = l2_flag ? c->norm_slot(nbeh, sb) : nullptr;
-    }
-    n.Bnew = c->Bnew;
-    n.out_behind = c->core_slot(sb);
-    n.out_ahead = c->lab[c->lab_cur ^ 1];
-    n.metrics = c->metrics + 2 * (size_t)step;
-    n.dbg = (c->debug || mode == 1) ? c->dbg : nullptr;
-    n.Bdirect = Bdirect_dev;
-    n.svd_stop2 = c->svd_stop2;
-    n.stop_after_update = mode == 1;
-    if (trunc_policy == TNML_TRUNC_ADAPTIVE && mode == 0) { n.trunc_thr = c->trunc_thr; n.left_dir = left_dir; n.m_out = c->status + 1; }
-    if (mode == 1) { n.Bnew = c->Bscr2; n.Nh_new = nullptr; }
-    n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + kDbgSigma + 5 : nullptr;
-    n.status = c->status;
-    n.counters = c->counters;
     prof_begin(c);
     { int rc = run_narrow(c, n, npath); if (rc) return rc; }
     prof_end(c, 3);
@@ -901,6 +922,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     HIP_TRY(hipMemcpy(&st, c->status, sizeof(int), hipMemcpyDeviceToHost));
     if (st) {
       HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
+      if (st & 4) return fail(TNML_ERR_STATE, "internal: helper workgroups of a fused step never arrived (status %d)", st);
       if (st & 1) return fail(TNML_ERR_NONFINITE, "non-finite values reached the bond update / SVD (status %d)", st);
       return fail(TNML_ERR_NONFINITE, "Jacobi SVD did not converge (status %d)", st);
     }

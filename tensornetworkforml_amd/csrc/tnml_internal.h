@@ -86,6 +86,16 @@ struct NarrowParams {
   unsigned long long *counters;  // [0] += jacobi sweeps, [1] += SVDs, [2] += jacobi rounds (always on)
   const float *Bdirect;    // if set: the merged tensor (relative layout) is given, the two cores are not read
   int stop_after_update;   // 1: return after B_new (standalone update_B / compute_L2_reg; needs dbg)
+  // fused launch (single GPU, in-LDS path): workgroups 1.. of the same launch reduce the gradient slabs and
+  // compute the merged tensor and the L2 term slice by slice; workgroup 0 waits for them on `sync`
+  int fused;               // 1: gridDim.x = 1 + nred (+ D*D slice workgroups unless prep_ready)
+  int prep_ready;          // prepB / prepG were produced by the preceding wide launch
+  const float *slabs;      // [nslabs][slab_stride]
+  int nslabs, slab_stride, nred;
+  float *red_out;          // == red
+  float *prepB;            // [bsize] merged tensor (float), written by the slice workgroups
+  double *prepG;           // [bsize] Ln.B.Rn
+  unsigned *sync;          // arrival counter, zero between launches
   double trunc_thr;        // > 0: adaptive truncation threshold on cumsum(S) / sum(S); m is then the cap
   int left_dir;            // direction (only read when trunc_thr > 0: the output strides follow the kept rank)
   int *m_out;              // device int receiving the kept rank (adaptive truncation), may be nullptr
@@ -104,10 +114,20 @@ void launch_env_chain(const ChainSite *sites_dev, int n_sites, const float *core
                       const float *X, float *env_base, float *f, int b, int b_pad, int L, int Mmax,
                       float *logmax_out, hipStream_t st);
 constexpr int kChainSamplesPerBlock = 16;
-void launch_wide(const WideParams &p, int nblk, hipStream_t st);
+// slice-wise pre-computation of the merged tensor and its L2 term (small_gemm_device.h: prep_slice_block)
+struct PrepParams {
+  CoreView lab, pl;        // as NarrowParams
+  const double *Nh, *Ng;
+  int h, g, s, L, l2_flag;
+  float *prepB;
+  double *prepG;
+};
+
+// returns true when the launch carried the D*D slice workgroups that fill prep.prepB / prep.prepG (MFMA kernel only)
+bool launch_wide(const WideParams &p, int nblk, const PrepParams *prep, hipStream_t st);
 void launch_f_only(const WideParams &p, int nblk, hipStream_t st);
 void launch_reduce(const float *slabs, int nblk, int slab_stride, int n, float *red, hipStream_t st);
-void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st);
+void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st);   // grid = p.fused ? 1 + p.nred + 4 : 1
 // Large-tensor path of the same step (kernels_big.hip): HBM scratch, n = min(rows, cols) <= 128.
 struct BigScratch {
   float *Bf;          // [bmax]   merged tensor

@@ -39,6 +39,8 @@ def stamp_line(tag, sc):
         print('   wide kernel WG0: x-stage %d / operand stage %d / f+env MFMA %d / activation %d / gP %d / dB MFMA+store %d cycles (own activation %d)' % tuple(sc[22:29]))
     if len(sc) > 32 and sc[29] > 0:
         print('   round-timing experiment (cycles per round): full %d / no G items %d / no V items %d / workers only %d' % tuple(sc[29:33]))
+    if len(sc) > 38 and sc[33] > 0:
+        print('   fused launch, 10 ns ticks after workgroup 0 started: wait over %d | reduce helpers %d..%d | slice helpers %d..%d | polls %d' % tuple(sc[33:39]))
     if len(sc) > 13:
         print('   post split: sort %d / cores %d / norm env + metrics %d cycles' % (sc[11], sc[12], sc[13]))
 
