@@ -213,26 +213,39 @@ def main():
         one_pass()
         one_pass()
         ctx.profile_enable(False)
-        names = ['env_chain_kernel', 'wide_step_kernel', 'reduce_slabs_kernel', 'narrow_step_kernel']
+        # the wide kernel is the MFMA formulation whenever its tile operands fit LDS (all configs but c5); on one GPU
+        # the slab reduction rides inside the narrow launch (helper workgroups), so reduce_slabs_kernel shows 0 launches
+        wide_name = 'wide_step_kernel' if args.config == 'c5' else 'wide_step_mfma_kernel'
+        names = ['env_chain_kernel', wide_name, 'reduce_slabs_kernel', 'narrow_step_kernel']
         kern = {}
         for i, nm in enumerate(names):
             ms, n = ctx.profile_get(i)
             kern[nm] = {'avg_us': 1e3 * ms / max(n, 1), 'launches': n, 'total_ms': ms}
         out['kernels'] = kern
         bstep = bytes_per_step(b, M, D, L)
-        wide_us = kern['wide_step_kernel']['avg_us']
+        wide_us = kern[wide_name]['avg_us']
         ach = bstep / (wide_us * 1e-6) / 1e9
         # HBM traffic of that kernel from committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
         # runs of this command; gfx950 correction: FETCH_SIZE counts half of a coalesced read stream)
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_%s.json' % args.config)
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_%s.json' % args.config)
         if os.path.exists(pmc):
-            w = json.load(open(pmc)).get('wide_step_kernel', {})
+            w = json.load(open(pmc)).get(wide_name, {})
             if 'FETCH_SIZE' in w and 'WRITE_SIZE' in w:
                 traffic = (2.0 * w['FETCH_SIZE']['mean_KB'] + w['WRITE_SIZE']['mean_KB']) * 1024.0
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'wide_step_kernel', 'achieved': ach, 'peak': HBM_PEAK_GBS,
+        # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary of this command (the HIP
+        # event figure above brackets one isolated launch and carries its ~3 us of launch latency)
+        rocprof_us = None
+        kst = os.path.join(ROOT, 'profiles', 'r01_kernel_stats_%s.csv' % args.config)
+        if os.path.exists(kst):
+            import csv
+            for row in csv.DictReader(open(kst)):
+                if wide_name + '(' in row['Name'] or row['Name'].split('(')[0].endswith(wide_name):
+                    rocprof_us = float(row['AverageNs']) / 1e3
+        out['roofline'] = {'bound': 'hbm', 'kernel': wide_name, 'achieved': ach, 'peak': HBM_PEAK_GBS,
                            'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                           'algorithmic_bytes_per_launch': bstep,
+                           'algorithmic_bytes_per_launch': bstep, 'kernel_avg_us_hip_events': wide_us,
+                           'kernel_avg_us_rocprofv3': rocprof_us,
                            'whole_step_GBs': bstep * value / 1e9}
     elif dist is not None and not args.no_kernel_profile:
         # keep the collectives of the profiling passes matched on every rank

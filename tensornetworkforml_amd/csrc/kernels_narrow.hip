@@ -126,7 +126,12 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
     q.prepB = p.prepB; q.prepG = p.prepG;
     prep_slice_block(q, blk - p.nred, smem_raw);
   }
-  __syncthreads();                      // every wave's stores are ordered before thread 0's agent-scope release below
+  // hand-off to workgroup 0 (other CU, possibly other XCD: L1 and L2 are not coherent across them): every storing
+  // wave drains its stores, the workgroup meets, then ONE agent-scope release (L2 write-back) bumps the counter;
+  // workgroup 0 acquires it and reads the data with agent-scope (sc1) loads (MI355X_MICROARCH.md, correctness
+  // boundaries)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (tid == 0) {
     if (p.stamps && p.counters) {      // diagnostic: first start and last finish of either helper role, 100 MHz ticks
       atomicMin(p.counters + (blk < p.nred ? 4 : 5), t_start);
