@@ -178,7 +178,10 @@ def main():
     finite = bool(np.isfinite(f).all() and np.isfinite(met).all())
 
     sweep_steps = args.steps * (N - 1)
-    value = sweep_steps * 1.0 / dt            # every rank performs the same steps on its own shard
+    # weak scaling: every rank performs the same sweep steps on its own shard of b samples, so the job's work unit is
+    # "one sweep step over one b-sample shard" and the whole-job aggregate is world x the common step rate
+    steps_per_s = sweep_steps * 1.0 / dt
+    value = world * steps_per_s
     out = {
         'metric': 'sweep-steps/sec, 28x28 MNIST-shaped, bond=%d, batch=%d per GPU' % (M, b),
         'value': value,
@@ -196,6 +199,8 @@ def main():
                                'trunc=%s, L2_flag=%s; pass = forward + %d-step sweep'
                                % (args.config, L, M, b, args.policy, hp['L2_flag'], N - 1),
                    'global_batch': b * world, 'sweep_steps_per_pass': N - 1, 'parallelism': 'dp%d' % world},
+        'value_definition': 'sweep steps per second x number of %d-sample shards (= GPUs) stepping in lock-step; '
+                            'global-batch sweep steps per second: %.1f' % (b, steps_per_s),
         'finite': finite,
         'breakdown': {'forward_ms': fwd_ms, 'h2d_batch_ms': h2d_ms,
                       'sweep_only_steps_per_s': (N - 1) / max(1e-3 * (1e3 * dt / args.steps - fwd_ms), 1e-9),
@@ -246,7 +251,7 @@ def main():
                            'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                            'algorithmic_bytes_per_launch': bstep, 'kernel_avg_us_hip_events': wide_us,
                            'kernel_avg_us_rocprofv3': rocprof_us,
-                           'whole_step_GBs': bstep * value / 1e9}
+                           'whole_step_GBs': bstep * steps_per_s / 1e9}
     elif dist is not None and not args.no_kernel_profile:
         # keep the collectives of the profiling passes matched on every rank
         one_pass()
