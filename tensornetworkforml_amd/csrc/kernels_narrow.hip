@@ -193,6 +193,12 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
       k.fB[e] = __hip_atomic_load(p.prepB + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (p.l2_flag) k.dG[e] = __hip_atomic_load(p.prepG + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+  } else if (p.prep_ready) {
+    // multi-GPU sequence (separate reduction + all-reduce): B and Ln.B.Rn still come from the wide launch's slices
+    for (int e = tid; e < Bs; e += NT) {
+      k.fB[e] = p.prepB[e];
+      if (p.l2_flag) k.dG[e] = p.prepG[e];
+    }
   } else if (!p.Bdirect) {
     for (int e = tid; e < h * D * s * L; e += NT) {
       const int l = e % L, q = e / L;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   TNML_STAMP(0);
   // ---- phase 1: B[h,dk,dk1,g,l] = sum_s lab(h,dk,s,l) * pl(s,dk1,g) ---------------------------
   const int RW = D * D * g * L;  // elements per behind-bond index
-  if (!p.Bdirect && !p.fused) {   // rows i = (h_, dk, l), columns j = (dk1, g_), inner index the shared bond
+  if (!p.Bdirect && !p.fused && !p.prep_ready) {   // rows i = (h_, dk, l), columns j = (dk1, g_), inner index the shared bond
     const int QW = D * g;
     small_gemm_f64(L, h * D, QW, s,
                    [&](int l, int i, int kk) { return (double)k.sLab[(i * s + kk) * L + l]; },
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 
   TNML_STAMP(1);
   // ---- phases 2-3: weight decay term ------------------------------------------------------------
-  if (p.l2_flag && !p.fused) {
+  if (p.l2_flag && !p.fused && !p.prep_ready) {
     // T = Nh^T . B over the behind bond:  T[e_, rest] = sum_a Nh[a, e_] B[a, rest]
     small_gemm_f64(1, h, RW, h,
                    [&](int, int i, int kk) { return k.dNh[kk * h + i]; },

@@ -766,7 +766,8 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     // reduce kernel, no boundary) and the merge / L2 products ride in the wide launch (or, with the plain-FMA wide
     // kernel, in the narrow launch as well); TNML_NARROW_FUSED=0 turns all of that off
     static const bool fuse_ok = !(getenv("TNML_NARROW_FUSED") && atoi(getenv("TNML_NARROW_FUSED")) == 0);
-    const bool fused = fuse_ok && !c->comm && npath == 0 && mode == 0 && !Bdirect_dev;
+    const bool prep_ok = fuse_ok && npath == 0 && mode == 0 && !Bdirect_dev;     // merge / L2 slices in the wide launch
+    const bool fused = prep_ok && !c->comm;                                       // + slab reduction in the narrow launch
     NarrowParams n{};
     n.L = L; n.D = D; n.h = h; n.g = g; n.s = s; n.m = m; n.bsize = (int)bsize;
     n.l2_flag = l2_flag ? 1 : 0; n.lr = lr; n.wd = weight_dec;
@@ -801,8 +802,9 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     n.stop_after_update = mode == 1;
     if (fused) {
       n.fused = 1; n.slabs = c->slabs; n.nslabs = nblk; n.slab_stride = c->slab_stride;
-      n.nred = ((int)bsize + kMetricSlots + 63) / 64; n.red_out = c->red; n.prepB = c->prepB; n.prepG = c->prepG; n.sync = c->sync;
+      n.nred = ((int)bsize + kMetricSlots + 63) / 64; n.red_out = c->red; n.sync = c->sync;
     }
+    n.prepB = c->prepB; n.prepG = c->prepG;
     if (trunc_policy == TNML_TRUNC_ADAPTIVE && mode == 0) { n.trunc_thr = c->trunc_thr; n.left_dir = left_dir; n.m_out = c->status + 1; }
     if (mode == 1) { n.Bnew = c->Bscr2; n.Nh_new = nullptr; }
     n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + kDbgSigma + 5 : nullptr;
@@ -850,7 +852,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     prep.lab = n.lab; prep.pl = n.pl; prep.Nh = n.Nh; prep.Ng = n.Ng; prep.h = h; prep.g = g; prep.s = s; prep.L = L;
     prep.l2_flag = n.l2_flag; prep.prepB = c->prepB; prep.prepG = c->prepG;
     prof_begin(c);
-    n.prep_ready = launch_wide(w, nblk, fused ? &prep : nullptr, c->stream) ? 1 : 0;
+    n.prep_ready = launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream) ? 1 : 0;
     prof_end(c, 1);
     // ---- reduce (+ all-reduce over the batch shards) -----------------------------------------
     if (!fused) {
