@@ -36,8 +36,16 @@ __device__ inline void block_sum3(double &a, double &b, double &c, double *scrat
   __syncthreads();
   if (lane == 0) { scratch[wave] = a; scratch[16 + wave] = b; scratch[32 + wave] = c; }
   __syncthreads();
-  a = 0; b = 0; c = 0;
-  for (int w = 0; w < nw; ++w) { a += scratch[w]; b += scratch[16 + w]; c += scratch[32 + w]; }
+  // every wave combines the (<= 16) wave partials with the same shuffle tree: identical result in all threads
+  a = lane < nw ? scratch[lane] : 0.0;
+  b = lane < nw ? scratch[16 + lane] : 0.0;
+  c = lane < nw ? scratch[32 + lane] : 0.0;
+  for (int off = 8; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off);
+    b += __shfl_xor(b, off);
+    c += __shfl_xor(c, off);
+  }
+  a = __shfl(a, 0); b = __shfl(b, 0); c = __shfl(c, 0);
   __syncthreads();
 }
 
@@ -157,6 +165,12 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 
   unsigned long long t_c0 = 0, t_r0 = 0, t_c1 = 0, t_c2 = 0, t_c2b = 0, t_c2c = 0;
   unsigned long long t_p[5] = {0, 0, 0, 0, 0};
+#ifdef TNML_EXP_FINE_STAMPS
+  unsigned long long t_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define XSTAMP(i) if (p.stamps && tid == 0) t_x[i] = __builtin_amdgcn_s_memtime()
+#else
+#define XSTAMP(i)
+#endif
 #define TNML_STAMP(i) if (p.stamps && tid == 0) t_p[i] = __builtin_amdgcn_s_memtime()
   if (p.stamps && tid == 0) { t_c0 = __builtin_amdgcn_s_memtime(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
   // ---- phase 0: stage the two cores and the norm environments ---------------------------------
@@ -248,9 +262,19 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   }
   TNML_STAMP(2);
   double sumB = 0.0, sumD = 0.0, l2 = 0.0;
-  for (int e = tid; e < Bs; e += NT) {
+  constexpr int kMaxPer = 8;                              // Bs <= 8192 in this kernel (LDS budget)
+  float redv[kMaxPer];
+#pragma unroll
+  for (int u = 0; u < kMaxPer; ++u) {                     // all loads of the reduced gradient in flight together
+    const int e = tid + u * NT;
+    redv[u] = e < Bs ? ldred(e) : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < kMaxPer; ++u) {
+    const int e = tid + u * NT;
+    if (e >= Bs) break;
     const double bv = (double)k.fB[e];
-    const double raw = (double)ldred(e);
+    const double raw = (double)redv[u];
     double wdterm;
     if (p.l2_flag) {
       const double gv = k.dG[e];
@@ -269,7 +293,9 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     sumB += fabs(bv);
     sumD += fabs(dv);
   }
+  XSTAMP(0);
   block_sum3(sumB, sumD, l2, k.dRed);
+  XSTAMP(1);
 
   // ---- phase 5: clip + update (Network_class.py:755-761) ----------------------------------------
   double factor = (double)p.lr;
@@ -293,6 +319,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
       sc[2] = sumD;
     }
   }
+  XSTAMP(2);
   __syncthreads();   // dT/dG are dead from here on; Z aliases them
   if (p.stop_after_update) {                       // standalone update_B / compute_L2_reg
     if (tid == 0 && p.metrics) {
@@ -308,28 +335,68 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   // ---- phase 6: Gram matrix in float64 (padded to ne x ne with a zero row/column), V = I ----------
   //   W(x, kk) = short_rows ? Bm[kk][x] : Bm[x][kk]   with Bm = B_new as (r x c) row-major
   double *G0 = k.Z, *G1 = k.Z + ne * ne, *V0 = k.Z + 2 * ne * ne;
-  for (int e = tid; e < ne * ne; e += NT) {           // zero fill (covers the padding) and V = I
-    G0[e] = 0.0;
-    V0[e] = (e / ne == e % ne) ? 1.0 : 0.0;
+  // float64 matrix and vector pipes of gfx950 both retire 16 FMA per cycle per SIMD, so the MFMA count per SIMD is
+  // what matters: the upper 16x16 tiles (G is symmetric) are cut into kGramSplit slices along the long index and
+  // the (tile, slice) items dealt round-robin to all 16 waves; slice partials land in the four ne x ne buffers of
+  // the Jacobi region and are summed in slice order (deterministic).
+  constexpr int kGramSplit = 4;
+  {
+    double *Pb[kGramSplit] = {G0, G1, V0, k.Z + 3 * ne * ne};
+    const int lane = tid & 63, wave = tid >> 6, rr = lane & 15, qq = lane >> 4;
+    const int tm = (n + 15) >> 4, ntile = tm * (tm + 1) / 2;
+    const int kchunk = ((len + kGramSplit - 1) / kGramSplit + 3) & ~3;       // multiple of the MFMA k = 4
+    for (int item = wave; item < ntile * kGramSplit; item += NT >> 6) {
+      const int ks = item % kGramSplit;
+      int t = item / kGramSplit, ti = 0;
+      while (t >= tm - ti) { t -= tm - ti; ++ti; }
+      const int tj = ti + t;
+      const int i0 = ti << 4, j0 = tj << 4;
+      const int ia = min(i0 + rr, n - 1), jb = min(j0 + rr, n - 1);
+      const bool va = i0 + rr < n, vb = j0 + rr < n;
+      const int k_lo = ks * kchunk, k_hi = min(len, k_lo + kchunk);
+      dvec4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      for (int k0 = k_lo; k0 < k_hi; k0 += 8) {
+        double av[2], bv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int kk = k0 + 4 * u + qq;
+          const bool vk = kk < k_hi;
+          const int kc = vk ? kk : k_hi - 1;
+          // rows of the padded copy (stride c + 1) keep the 16 lanes of an operand on 16 different banks
+          const float fa = short_rows ? k.fBp[ia * (c + 1) + kc] : k.fB[kc * c + ia];
+          const float fb = short_rows ? k.fBp[jb * (c + 1) + kc] : k.fB[kc * c + jb];
+          av[u] = (va && vk) ? (double)fa : 0.0;
+          bv[u] = (vb && vk) ? (double)fb : 0.0;
+        }
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
+        if (k0 + 4 < k_hi) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
+      }
+      const dvec4 acc = acc0 + acc1;
+      const int j = j0 + rr;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = i0 + qq + 4 * reg;
+        if (i < ne && j < ne) Pb[ks][i * ne + j] = (i < n && j < n) ? acc[reg] : 0.0;     // padding row / column = 0
+      }
+    }
+    __syncthreads();
+    XSTAMP(3);
+    // sum of the slices, in slice order, mirrored into the lower triangle (exact symmetry); tiles below the
+    // diagonal were never written
+    for (int e = tid; e < ne * ne; e += NT) {
+      const int i = e / ne, j = e - i * ne;
+      if ((i >> 4) <= (j >> 4)) {
+        const double v = ((Pb[0][e] + Pb[1][e]) + Pb[2][e]) + Pb[3][e];
+        if (i <= j) G0[e] = v;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < ne * ne; e += NT) {
+      const int i = e / ne, j = e - i * ne;
+      if (i > j) G0[e] = G0[j * ne + i];
+    }
   }
-  __syncthreads();
-  // rows of the padded copy (stride c + 1) keep the 16 lanes of an operand on 16 different banks
-  if (short_rows)
-    small_gemm_f64(1, n, n, len,
-                   [&](int, int i, int x) { return (double)k.fBp[i * (c + 1) + x]; },
-                   [&](int, int x, int j) { return (double)k.fBp[j * (c + 1) + x]; },
-                   [&](int, int i, int j, double v) { G0[i * ne + j] = v; });
-  else
-    small_gemm_f64(1, n, n, len,
-                   [&](int, int i, int x) { return (double)k.fB[x * c + i]; },
-                   [&](int, int x, int j) { return (double)k.fB[x * c + j]; },
-                   [&](int, int i, int j, double v) { G0[i * ne + j] = v; });
-  __syncthreads();
-  // exact symmetry (the two triangles come from different accumulation orders)
-  for (int e = tid; e < n * n; e += NT) {
-    const int i = e / n, j = e % n;
-    if (i < j) G0[j * ne + i] = G0[i * ne + j];
-  }
+  XSTAMP(4);
   // Tournament in POSITION space: the pairs of a round are always the positions (2k, 2k+1); after
   // the rotations every row/column moves to position pi(pos) of the next round (circle method:
   // position 0 fixed, top row shifts right, bottom row shifts left).  The move is free: the updated
@@ -346,8 +413,12 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   __syncthreads();
   TNML_STAMP(4);
   // scale G to trace ~ 1 by an exact power of two (undone on the eigenvalues in phase 8)
-  double tr = 0.0;
-  for (int j = 0; j < n; ++j) tr += G0[j * ne + j];
+  double tr = 0.0;                                        // n <= 64: one diagonal entry per lane, same tree in every wave
+  {
+    const int ln = tid & 63;
+    tr = ln < n ? G0[ln * ne + ln] : 0.0;
+    for (int off = 32; off > 0; off >>= 1) tr += __shfl_xor(tr, off);
+  }
   const int sc_exp = (tr > 0.0 && isfinite(tr)) ? __builtin_amdgcn_frexp_exp(tr) : 0;
   __syncthreads();
   for (int e = tid; e < ne * ne; e += NT) G0[e] = __builtin_amdgcn_ldexp(G0[e], -sc_exp);
@@ -416,11 +487,12 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 
   auto kept_scale = [&](const double *G) -> double {
     // (kKeptFrac * m-th largest diagonal entry)^2, block-wide; ends with a barrier
-    for (int j = tid; j < n; j += NT) {
+    const int i = tid & 63;
+    const double li = i < n ? G[i * ne + i] : 0.0;
+    for (int j = tid >> 6; j < n; j += NT >> 6) {         // one wave per entry, ballot = rank (n <= 64)
       const double lj = G[j * ne + j];
-      int rank = 0;
-      for (int i = 0; i < n; ++i) { const double li = G[i * ne + i]; rank += (li > lj) || (li == lj && i < j); }
-      if (rank == m - 1) k.dRed[60] = lj;
+      const int rank = __popcll(__ballot(i < n && ((li > lj) || (li == lj && i < j))));
+      if (i == 0 && rank == m - 1) k.dRed[60] = lj;
     }
     __syncthreads();
     const double lm = kKeptFrac * fmax(k.dRed[60], 0.0);
@@ -567,16 +639,15 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   // ---- phase 8: eigenvalues = diag(G), descending order -------------------------------------------
   for (int j = tid; j < n; j += NT) k.dLam[j] = __builtin_amdgcn_ldexp(fmax(Gc[j * ne + j], 0.0), sc_exp);
   __syncthreads();
-  for (int j = tid; j < n; j += NT) {
+  for (int j = tid >> 6; j < n; j += NT >> 6) {           // one wave per entry: lane i votes "i sorts before j" (n <= 64)
+    const int i = tid & 63;
     const double lj = k.dLam[j];
-    int rank = 0;
-#pragma unroll 8
-    for (int i = 0; i < n; ++i) {
-      const double li = k.dLam[i];
-      rank += (li > lj) || (li == lj && i < j);
+    const double li = i < n ? k.dLam[i] : 0.0;
+    const int rank = __popcll(__ballot(i < n && ((li > lj) || (li == lj && i < j))));
+    if (i == 0) {
+      k.sOrd[rank] = j;
+      if (p.dbg) p.dbg[4 * (size_t)Bs + rank] = sqrt(lj);
     }
-    k.sOrd[rank] = j;
-    if (p.dbg) p.dbg[4 * (size_t)Bs + rank] = sqrt(lj);
   }
   if (tid == 0) {
     if (p.counters) {
@@ -687,6 +758,11 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     p.stamps[0] = (double)(t_c1 - t_c0); p.stamps[1] = (double)(t_c2 - t_c1); p.stamps[2] = (double)(t_c3 - t_c2);
     p.stamps[3] = (double)(t_r3 - t_r0); p.stamps[4] = (double)sweeps; p.stamps[5] = (double)n;
     for (int i = 0; i < 5; ++i) p.stamps[9 + i] = (double)(t_p[i] - (i ? t_p[i - 1] : t_c0));
+#ifdef TNML_EXP_FINE_STAMPS
+    p.stamps[34] = (double)(t_x[0] - t_p[2]); p.stamps[35] = (double)(t_x[1] - t_x[0]); p.stamps[36] = (double)(t_x[2] - t_x[1]);
+    p.stamps[37] = (double)(t_p[3] - t_x[2]); p.stamps[38] = (double)(t_x[3] - t_p[3]); p.stamps[39] = (double)(t_x[4] - t_x[3]);
+    p.stamps[40] = (double)(t_p[4] - t_x[4]);
+#endif
     p.stamps[6] = (double)(t_c2b - t_c2); p.stamps[7] = (double)(t_c2c - t_c2b); p.stamps[8] = (double)(t_c3 - t_c2c);
   }
 

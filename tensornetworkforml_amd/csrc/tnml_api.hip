@@ -200,7 +200,7 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   c->metrics_cap = N;
   HIP_TRY(hipMalloc(&c->metrics, (size_t)c->metrics_cap * 2 * sizeof(float)));
   HIP_TRY(hipMalloc(&c->scal, 64 * sizeof(float)));
-  c->dbg_elems = 4 * c->bmax + kDbgSigma + 48;   // 4 tensors, sigma[kDbgSigma], 5 scalars, stamps
+  c->dbg_elems = 4 * c->bmax + kDbgSigma + 64;   // 4 tensors, sigma[kDbgSigma], 5 scalars, stamps
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
   HIP_TRY(hipMalloc(&c->status, 2 * sizeof(int)));      // [0] status word, [1] kept rank of the last adaptive step
   HIP_TRY(hipMemsetAsync(c->status, 0, 2 * sizeof(int), c->stream));
@@ -1027,9 +1027,9 @@ extern "C" int tnml_l2_term(tnml_ctx *c, const float *B_canon, int left_dir, flo
   const bool dbg_was = c->debug;
   c->debug = true;
   size_t nn = 0;
-  double sc[48];
+  double sc[64];
   rc = tnml_get_step_debug(c, TNML_DBG_L2_GRAD, grad_canon, capacity, &nn);
-  if (!rc) rc = tnml_get_step_debug(c, TNML_DBG_L2, sc, 48, &nn);
+  if (!rc) rc = tnml_get_step_debug(c, TNML_DBG_L2, sc, 64, &nn);
   c->debug = dbg_was;
   if (rc) return rc;
   *loss = sc[0];
@@ -1137,9 +1137,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
   if (c->last_bsize <= 0) return fail(TNML_ERR_STATE, "no step has run yet");
   HIP_TRY(hipSetDevice(c->device));
   const size_t Bs = c->last_bsize;
-  std::vector<double> hbuf(4 * Bs + kDbgSigma + 48);   // tensors, sigma, 5 scalars, 14 stamps
+  std::vector<double> hbuf(4 * Bs + kDbgSigma + 64);   // tensors, sigma, 5 scalars, 14 stamps
   HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, (4 * Bs + kDbgSigma + 5) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + kDbgSigma + 5, c->dbg + 4 * c->bmax + kDbgSigma + 5, 35 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + kDbgSigma + 5, c->dbg + 4 * c->bmax + kDbgSigma + 5, 51 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   auto tensor_out = [&](size_t block) -> int {
     if (capacity < Bs) return fail(TNML_ERR_ARG, "capacity too small");
@@ -1167,9 +1167,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
       if (n_out) *n_out = c->last_n;
       return TNML_OK;
     case TNML_DBG_L2:
-      if (capacity < 40) return fail(TNML_ERR_ARG, "capacity too small");
-      memcpy(out, hbuf.data() + 4 * Bs + kDbgSigma, 40 * sizeof(double));
-      if (n_out) *n_out = 40;
+      if (capacity < 56) return fail(TNML_ERR_ARG, "capacity too small");
+      memcpy(out, hbuf.data() + 4 * Bs + kDbgSigma, 56 * sizeof(double));
+      if (n_out) *n_out = 56;
       return TNML_OK;
   }
   return fail(TNML_ERR_ARG, "unknown debug selector %d", what);
