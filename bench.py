@@ -218,9 +218,10 @@ def main():
         one_pass()
         one_pass()
         ctx.profile_enable(False)
-        # the wide kernel is the MFMA formulation whenever its tile operands fit LDS (all configs but c5); on one GPU
+        # the wide kernel is the one-shot MFMA formulation whenever its tile operands fit LDS (all configs but c5, which
+        # streams the merged tensor through LDS in chunks); on one GPU
         # the slab reduction rides inside the narrow launch (helper workgroups), so reduce_slabs_kernel shows 0 launches
-        wide_name = 'wide_step_kernel' if args.config == 'c5' else 'wide_step_mfma_kernel'
+        wide_name = 'wide_step_mfma_tiled_kernel' if args.config == 'c5' else 'wide_step_mfma_kernel'
         names = ['env_chain_kernel', wide_name, 'reduce_slabs_kernel', 'narrow_step_kernel']
         kern = {}
         for i, nm in enumerate(names):

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBT) void big_update_kernel(NarrowParams p, double 
                                                         int nparts) {
   const int Bs = p.bsize;
   // identical summation tree in every block and on every rank: lanes stride the partials, then a fixed
-  // xor-shuffle tree (nparts <= 128)
+  // xor-shuffle tree
   __shared__ double sSum[3];
   if (threadIdx.x < 64) {
     double a_ = 0.0, b_ = 0.0, c_ = 0.0;
@@ -125,19 +125,22 @@ __global__ __launch_bounds__(kBT) void big_update_kernel(NarrowParams p, double 
 
 // ---- Gram matrix of the short side, float64 accumulation of the float32 B_new -----------------------------------
 //   W(i, x) = Bn[i * si + x * sx];  G[i][j] = sum_x W(i,x) W(j,x), 16x16 output tile per block, upper tiles only
+constexpr int kGramKS = 8;      // slices along the long index; the Jacobi kernel sums the partial matrices in slice order
 __global__ __launch_bounds__(256) void big_gram_kernel(const float *__restrict__ Bn, int n, int len, int si, int sx,
-                                                      double *__restrict__ G) {
-  const int ti = blockIdx.y, tj = blockIdx.x;
+                                                      double *__restrict__ Gpart) {
+  const int ti = blockIdx.y, tj = blockIdx.x, ks = blockIdx.z;
   if (ti > tj) return;
   __shared__ float sA[16][65], sB[16][65];
   const int r = threadIdx.x >> 4, cidx = threadIdx.x & 15;
+  const int chunk = ((len + kGramKS - 1) / kGramKS + 63) & ~63;
+  const int x_lo = ks * chunk, x_hi = min(len, x_lo + chunk);
   double acc = 0.0;
-  for (int x0 = 0; x0 < len; x0 += 64) {
+  for (int x0 = x_lo; x0 < x_hi; x0 += 64) {
     for (int e = threadIdx.x; e < 16 * 64; e += 256) {
       const int row = e >> 6, x = e & 63;
       const int ia = ti * 16 + row, ib = tj * 16 + row;
-      sA[row][x] = (ia < n && x0 + x < len) ? Bn[(size_t)ia * si + (size_t)(x0 + x) * sx] : 0.f;
-      sB[row][x] = (ib < n && x0 + x < len) ? Bn[(size_t)ib * si + (size_t)(x0 + x) * sx] : 0.f;
+      sA[row][x] = (ia < n && x0 + x < x_hi) ? Bn[(size_t)ia * si + (size_t)(x0 + x) * sx] : 0.f;
+      sB[row][x] = (ib < n && x0 + x < x_hi) ? Bn[(size_t)ib * si + (size_t)(x0 + x) * sx] : 0.f;
     }
     __syncthreads();
 #pragma unroll 16
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(256) void big_gram_kernel(const float *__restrict__
     __syncthreads();
   }
   const int i = ti * 16 + r, j = tj * 16 + cidx;
+  double *G = Gpart + (size_t)ks * n * n;
   if (i < n && j < n && i <= j) { G[(size_t)i * n + j] = acc; G[(size_t)j * n + i] = acc; }
 }
 
@@ -159,7 +163,7 @@ __device__ inline int elem_slot(int a, int b, int np) {       // element (a, b) 
 }
 
 struct BigJacobiArgs {
-  const double *G;       // n x n, row-major (input)
+  const double *G;       // kGramKS partial n x n matrices, row-major (input)
   int n, m;
   double stop2;
   double2 *rotlog;       // [round][np] (c, s)
@@ -185,8 +189,12 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
     int P = 0, rem = b;
     while (rem >= np - P) { rem -= np - P; ++P; }
     const int Q = P + rem;
-    const double e11 = a.G[(size_t)(2 * P) * n + 2 * Q], e12 = a.G[(size_t)(2 * P) * n + 2 * Q + 1];
-    const double e21 = a.G[(size_t)(2 * P + 1) * n + 2 * Q], e22 = a.G[(size_t)(2 * P + 1) * n + 2 * Q + 1];
+    double e11 = 0.0, e12 = 0.0, e21 = 0.0, e22 = 0.0;
+    for (int ks = 0; ks < kGramKS; ++ks) {                 // partial Gram matrices, fixed order
+      const double *Gp = a.G + (size_t)ks * n * n;
+      e11 += Gp[(size_t)(2 * P) * n + 2 * Q]; e12 += Gp[(size_t)(2 * P) * n + 2 * Q + 1];
+      e21 += Gp[(size_t)(2 * P + 1) * n + 2 * Q]; e22 += Gp[(size_t)(2 * P + 1) * n + 2 * Q + 1];
+    }
     G0[4 * b] = e11; G0[4 * b + 1] = e12; G0[4 * b + 2] = e21; G0[4 * b + 3] = e22;
     if (P == Q) trp += e11 + e22;
   }
@@ -395,32 +403,32 @@ __global__ __launch_bounds__(64) void big_replay_kernel(const float *__restrict_
   }
 }
 
-// ---- eigenvalue order, the two new cores, metrics ---------------------------------------------------------------
-__global__ __launch_bounds__(1024) void big_finish_kernel(NarrowParams p, const double *__restrict__ lam, const double *__restrict__ VW,
-                                                         const int *__restrict__ info, double *__restrict__ ws, float *__restrict__ Cb, int *__restrict__ m_dev) {
-  __shared__ double sLam[128], sSq[2][128];
-  __shared__ int sOrd[128];
-  const int tid = threadIdx.x, NT = 1024;
-  const int D = kD, h = p.h, g = p.g, L = p.L, Bs = p.bsize;
-  const int r = D * h, c = D * g * L;
-  const bool short_rows = r <= c;
-  const int n = short_rows ? r : c, len = short_rows ? c : r;
-  for (int j = tid; j < n; j += NT) sLam[j] = lam[j];
+// ---- eigenvalue order, kept rank, sigma^(+-1/2), metrics (one small block) ---------------------------------------
+//   lam3: [0,128) eigenvalues by position (in), [128,256) sigma^(1/2) and [256,384) sigma^(-1/2) of the kept columns (out)
+//   info: [3] kept rank, [4..) position of the sp-th largest eigenvalue (out)
+__global__ __launch_bounds__(128) void big_order_kernel(NarrowParams p, double *__restrict__ lam3, int *__restrict__ info,
+                                                       double *__restrict__ ws) {
+  __shared__ double sLam[kBigMaxN];
+  __shared__ int sOrd[kBigMaxN];
+  __shared__ int sM;
+  const int tid = threadIdx.x, NT = 128;
+  const int D = kD, L = p.L, Bs = p.bsize;
+  const int r = D * p.h, c = D * p.g * L;
+  const int n = r <= c ? r : c;
+  for (int j = tid; j < n; j += NT) sLam[j] = lam3[j];
   __syncthreads();
   for (int j = tid; j < n; j += NT) {
     const double lj = sLam[j];
     int rank = 0;
     for (int i = 0; i < n; ++i) { const double li = sLam[i]; rank += (li > lj) || (li == lj && i < j); }
     sOrd[rank] = j;
+    info[4 + rank] = j;
     ws[4 * (size_t)Bs + rank] = sqrt(lj);
   }
   __syncthreads();
-  // adaptive truncation (see narrow_step_kernel)
-  __shared__ int sM;
-  int ob_s_h = p.ob_s_h, ob_s_d = p.ob_s_d, oa_s_d = p.oa_s_d, oa_s_g = p.oa_s_g;
   if (tid == 0) {
     int me = p.m;
-    if (p.trunc_thr > 0.0) {
+    if (p.trunc_thr > 0.0) {                       // adaptive truncation (see narrow_step_kernel)
       double tot = 0.0;
       for (int j = 0; j < n; ++j) tot += sqrt(sLam[sOrd[j]]);
       double cum = 0.0;
@@ -434,44 +442,7 @@ __global__ __launch_bounds__(1024) void big_finish_kernel(NarrowParams p, const 
       if (p.m_out) *p.m_out = me;
     }
     sM = me;
-    m_dev[0] = me;
-  }
-  __syncthreads();
-  const int m = sM;
-  if (p.trunc_thr > 0.0) { if (!p.left_dir) { ob_s_h = D * m; ob_s_d = m; } else { oa_s_d = m * L; oa_s_g = D * m * L; } }
-  const double lam_max = sLam[sOrd[0]];
-  for (int sp = tid; sp < m; sp += NT) {
-    const double l_ = sLam[sOrd[sp]];
-    const bool ok = l_ > 1e-300 && l_ > 1e-30 * lam_max;
-    const double sq = ok ? sqrt(sqrt(l_)) : 0.0;
-    sSq[0][sp] = sq; sSq[1][sp] = ok ? 1.0 / sq : 0.0;
-  }
-  __syncthreads();
-  // short-side factor: V[kk][pos_j] sigma_j^(1/2)
-  for (int e = tid; e < n * m; e += NT) {
-    const int kk = e / m, sp = e % m;
-    const float v = (float)(VW[(size_t)kk * n + sOrd[sp]] * sSq[0][sp]);
-    if (short_rows) {
-      Cb[kk * m + sp] = v;
-      p.out_behind[(kk / D) * ob_s_h + (kk % D) * ob_s_d + sp * p.ob_s_m] = v;
-    } else {
-      const int l = kk % L, q = kk / L;
-      p.out_ahead[sp * p.oa_s_m + (q / g) * oa_s_d + (q % g) * oa_s_g + l] = v;
-    }
-  }
-  // long-side factor: (W^T V)[x][pos_j] sigma_j^(-1/2)
-  for (int e = tid; e < len * m; e += NT) {
-    const int x = e / m, sp = e % m;
-    const float v = (float)(VW[(size_t)(n + x) * n + sOrd[sp]] * sSq[1][sp]);
-    if (short_rows) {            // x = (dk1, g_, l)
-      const int l = x % L, q = x / L;
-      p.out_ahead[sp * p.oa_s_m + (q / g) * oa_s_d + (q % g) * oa_s_g + l] = v;
-    } else {                     // x = (h_, dk)
-      Cb[x * m + sp] = v;
-      p.out_behind[(x / D) * ob_s_h + (x % D) * ob_s_d + sp * p.ob_s_m] = v;
-    }
-  }
-  if (tid == 0) {
+    info[3] = me;
     double *sc = ws + 4 * (size_t)Bs + kDbgSigma;
     sc[3] = (double)info[1];
     sc[4] = (double)n;
@@ -481,6 +452,41 @@ __global__ __launch_bounds__(1024) void big_finish_kernel(NarrowParams p, const 
       p.metrics[0] = (float)((double)p.red[Bs] * inv);
       p.metrics[1] = (float)((double)p.red[Bs + 1] * inv / (double)L);
       if (p.red[Bs + 2] != 0.f) atomicOr(p.status, 1);
+    }
+  }
+  __syncthreads();
+  const double lam_max = sLam[sOrd[0]];
+  for (int sp = tid; sp < sM; sp += NT) {
+    const double l_ = sLam[sOrd[sp]];
+    const bool ok = l_ > 1e-300 && l_ > 1e-30 * lam_max;
+    const double sq = ok ? sqrt(sqrt(l_)) : 0.0;
+    lam3[kBigMaxN + sp] = sq;
+    lam3[2 * kBigMaxN + sp] = ok ? 1.0 / sq : 0.0;
+  }
+}
+
+// ---- the two new cores: short side V[kk][pos_j] sigma_j^(1/2), long side (W^T V)[x][pos_j] sigma_j^(-1/2) ------------
+__global__ __launch_bounds__(kBT) void big_cores_kernel(NarrowParams p, const double *__restrict__ lam3, const int *__restrict__ info,
+                                                       const double *__restrict__ VW, float *__restrict__ Cb) {
+  const int D = kD, h = p.h, g = p.g, L = p.L;
+  const int r = D * h, c = D * g * L;
+  const bool short_rows = r <= c;
+  const int n = short_rows ? r : c, len = short_rows ? c : r;
+  const int m = info[3];
+  const int *ord = info + 4;
+  int ob_s_h = p.ob_s_h, ob_s_d = p.ob_s_d, oa_s_d = p.oa_s_d, oa_s_g = p.oa_s_g;
+  if (p.trunc_thr > 0.0) { if (!p.left_dir) { ob_s_h = D * m; ob_s_d = m; } else { oa_s_d = m * L; oa_s_g = D * m * L; } }
+  for (int e = blockIdx.x * kBT + threadIdx.x; e < (n + len) * m; e += gridDim.x * kBT) {
+    const int row = e / m, sp = e - row * m;
+    const bool is_short = row < n;
+    const float v = (float)(VW[(size_t)row * n + ord[sp]] * lam3[(is_short ? 1 : 2) * kBigMaxN + sp]);
+    const int x = is_short ? row : row - n;              // index on its own side
+    if (is_short == short_rows) {                        // behind core: index (h_, dk)
+      Cb[x * m + sp] = v;
+      p.out_behind[(x / D) * ob_s_h + (x % D) * ob_s_d + sp * p.ob_s_m] = v;
+    } else {                                             // ahead core: index (dk1, g_, l)
+      const int l = x % L, q = x / L;
+      p.out_ahead[sp * p.oa_s_m + (q / g) * oa_s_d + (q % g) * oa_s_g + l] = v;
     }
   }
 }
@@ -522,25 +528,28 @@ void launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   const bool short_rows = r <= c;
   const int n = short_rows ? r : c, len = short_rows ? c : r;
   const int si = short_rows ? c : 1, sx = short_rows ? 1 : c;
-  const int nb = std::min((Bs + kBT - 1) / kBT, 128);
+  const int nbe = std::min((Bs + kBT - 1) / kBT, 2048);          // one element per thread
+  const int nb = std::min((Bs + kBT - 1) / kBT, kBigParts);      // kernels that leave block partials
   const float *Bf = p.Bdirect;
   if (!Bf) {
-    hipLaunchKernelGGL(big_merge_kernel, dim3(nb), dim3(kBT), 0, st, p, s.Bf);
+    hipLaunchKernelGGL(big_merge_kernel, dim3(nbe), dim3(kBT), 0, st, p, s.Bf);
     Bf = s.Bf;
   }
   double *ws = p.dbg;                          // the capture block doubles as the workspace of this path
-  if (p.l2_flag) hipLaunchKernelGGL(big_l2_T_kernel, dim3(nb), dim3(kBT), 0, st, p, Bf, s.T);
+  if (p.l2_flag) hipLaunchKernelGGL(big_l2_T_kernel, dim3(nbe), dim3(kBT), 0, st, p, Bf, s.T);
   hipLaunchKernelGGL(big_wd_kernel, dim3(nb), dim3(kBT), 0, st, p, Bf, s.T, ws, s.part);
   hipLaunchKernelGGL(big_update_kernel, dim3(nb), dim3(kBT), 0, st, p, ws, s.part, nb);
   if (p.stop_after_update) return;
   const int nt = (n + 15) / 16;
-  hipLaunchKernelGGL(big_gram_kernel, dim3(nt, nt), dim3(256), 0, st, p.Bnew, n, len, si, sx, s.gram);
+  hipLaunchKernelGGL(big_gram_kernel, dim3(nt, nt, kGramKS), dim3(256), 0, st, p.Bnew, n, len, si, sx, s.gram);
   BigJacobiArgs a{};
   a.G = s.gram; a.n = n; a.m = p.m; a.stop2 = p.svd_stop2; a.rotlog = s.rotlog; a.lam = s.lam; a.info = s.info;
   a.counters = p.counters; a.status = p.status;
   hipLaunchKernelGGL(big_jacobi_kernel, dim3(1), dim3(1024), big_jacobi_lds_bytes(n), st, a);
   hipLaunchKernelGGL(big_replay_kernel, dim3(n + len), dim3(64), 0, st, p.Bnew, n, len, si, sx, s.rotlog, s.info, s.VW);
-  hipLaunchKernelGGL(big_finish_kernel, dim3(1), dim3(1024), 0, st, p, s.lam, s.VW, s.info, ws, s.Cb, s.info + 3);
+  hipLaunchKernelGGL(big_order_kernel, dim3(1), dim3(128), 0, st, p, s.lam, s.info, ws);
+  hipLaunchKernelGGL(big_cores_kernel, dim3(std::min(((n + len) * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, st, p, s.lam, s.info,
+                     s.VW, s.Cb);
   if (p.Nh_new) {
     const int nb2 = std::min((p.h * D * p.m + kBT - 1) / kBT, 256);
     hipLaunchKernelGGL(big_norm_T_kernel, dim3(nb2), dim3(kBT), 0, st, p, s.Cb, s.T2, s.info + 3);

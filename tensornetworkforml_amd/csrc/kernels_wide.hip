@@ -9,6 +9,8 @@
 // the contiguous axis, so a wave reads 64 consecutive samples of one bond index); f [L][b_pad].
 #include <cstdlib>
 
+#include <string>
+
 #include "tnml_internal.h"
 #include "small_gemm_device.h"
 
@@ -696,6 +698,262 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_kernel(WideParams
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Wide step kernel, MFMA formulation for tiles whose operands do not fit LDS at once (bond 50 with ten labels:
+// the previous step's merged tensor alone is 400 KB).  Same three products as wide_step_mfma_kernel, with
+//   * the merged tensor B' streamed through LDS in chunks of 16 rows i = (h', d) (asynchronous global -> LDS
+//     loads straight into the padded layout); every wave keeps the partial f of its (label, sample-tile) pairs in
+//     registers across the chunks;
+//   * the bond gradient as ONE GEMM over the flattened column index n = (j, l):
+//        dB[i, n] = sum_s P[i, s] (Q[j, s] g[l, s]),
+//     the label factor applied to the B operand on the fly (no per-label operand array), and 16 consecutive n per
+//     tile so that the slab is written in 64-byte runs;
+//   * the staging buffers of the first phase (environments, extension core) aliased with the chunk buffer.
+// ------------------------------------------------------------------------------------------
+struct WideTiledSmem { float *sX, *sF, *sGl, *sPp, *sQp, *sH, *sP, *sQ, *U, *rH, *rGp, *rG, *rA, *sA, *sBc; size_t floats; };
+__host__ __device__ inline WideTiledSmem wide_tiled_carve(float *base, WideMfmaDims &d, int L, int h, int hp, int gp, int g) {
+  WideTiledSmem w;
+  d.RS = (d.JP * L) | 1;
+  float *q = base;
+  w.sX = q; q += 3 * kTS * kD;
+  w.sF = q; q += L * kTS;
+  w.sGl = q; q += L * kTS;
+  w.sPp = q; q += d.IP * kTSP;
+  w.sQp = q; q += d.JP * kTSP;
+  w.sH = q; q += up(h, 16) * kTSP;
+  w.sP = q; q += d.I3 * kTSP;
+  w.sQ = q; q += d.J3 * kTSP;
+  w.U = q;
+  constexpr int RPI = 64 / kTS;
+  float *a = q;
+  w.rH = a; a += up(hp, RPI) * kTS;
+  w.rGp = a; a += up(gp, RPI) * kTS;
+  w.rG = a; a += up(g, RPI) * kTS;
+  w.rA = a; a += up(hp * kD * h, 64);
+  w.sA = a; a += d.KA * d.HS;
+  const size_t ua = (size_t)(a - q), ub = (size_t)16 * d.RS + 64;
+  w.sBc = q;
+  q += ua > ub ? ua : ub;
+  w.floats = (size_t)(q - base);
+  return w;
+}
+
+__global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(WideParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  WideMfmaDims dm = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
+  const WideTiledSmem w = wide_tiled_carve(smem, dm, p.L, p.h, p.hp, p.gp, p.g);
+  const int tid = threadIdx.x, NT = kMfmaThreads;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int s0 = blockIdx.x * kTS;
+  const int L = p.L, h = p.h, g = p.g, hp = p.hp, gp = p.gp;
+  const int nI = hp * kD, nJ = kD * gp;
+  constexpr int ST = kTS / 16;
+  constexpr int NWV = kMfmaThreads / 64;
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+#define GLDS(gp_, lp_) __builtin_amdgcn_global_load_lds((gptr_t)(gp_), (lptr_t)(lp_), 4, 0, 0)
+  constexpr int RPI = 64 / kTS;
+  const int half = lane / kTS, col = lane % kTS;
+  const bool haveH = p.Hprev && !p.first_ext && (p.do_f || p.do_ext);
+
+  // ---- phase A: stage the per-sample operands and the extension core; padded operand arrays; env extension ----
+  for (int c = wave; c < 3 * kTS * kD / 64; c += NWV) {
+    const int which = c / (kTS * kD / 64), off = (c % (kTS * kD / 64)) * 64;
+    const float *src = which == 0 ? p.x_km1 : (which == 1 ? p.x_k : p.x_kp1);
+    if (src) GLDS(src + (size_t)s0 * kD + off + lane, w.sX + c * 64);
+  }
+  if (haveH)
+    for (int pr = wave; pr < up(hp, RPI) / RPI; pr += NWV)
+      GLDS(p.Hprev + (size_t)min(RPI * pr + half, hp - 1) * p.b_pad + s0 + col, w.rH + pr * 64);
+  if (p.do_f && p.Gprev)
+    for (int pr = wave; pr < up(gp, RPI) / RPI; pr += NWV)
+      GLDS(p.Gprev + (size_t)min(RPI * pr + half, gp - 1) * p.b_pad + s0 + col, w.rGp + pr * 64);
+  if (p.Gcur)
+    for (int pr = wave; pr < up(g, RPI) / RPI; pr += NWV)
+      GLDS(p.Gcur + (size_t)min(RPI * pr + half, g - 1) * p.b_pad + s0 + col, w.rG + pr * 64);
+  if (p.do_ext) {
+    const int nA = nI * h;
+    for (int c = wave; c < up(nA, 64) / 64; c += NWV) {
+      const int idx = min(c * 64 + lane, nA - 1);
+      const int i = idx / h, o = idx - i * h;
+      GLDS(p.ext_core.base + (i >> 1) * p.ext_core.s_in + (i & 1) * p.ext_core.s_d + o * p.ext_core.s_out, w.rA + c * 64);
+    }
+  }
+  if (!p.do_f)
+    for (int e = tid; e < L * kTS; e += NT) w.sF[e] = p.f[(size_t)(e / kTS) * p.b_pad + s0 + (e % kTS)];
+  if (!p.do_ext)
+    for (int e = tid; e < up(h, 16) * kTS; e += NT) {
+      const int sl = e % kTS, hn = e / kTS;
+      w.sH[hn * kTSP + sl] = hn < h ? (p.Hcur ? p.Hcur[(size_t)hn * p.b_pad + s0 + sl] : 1.0f) : 0.f;
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float *sXm = w.sX, *sXk = w.sX + kTS * kD, *sXp = w.sX + 2 * kTS * kD;
+  if (p.do_f || p.do_ext)
+    for (int e = tid; e < dm.IP * kTS; e += NT) {       // P'[i][s] = H'[h'][s] x_{k-1}[s][d]
+      const int sl = e % kTS, i = e / kTS;
+      float v = 0.f;
+      if (i < nI) v = (haveH ? w.rH[(i >> 1) * kTS + sl] : 1.0f) * sXm[sl * kD + (i & 1)];
+      w.sPp[i * kTSP + sl] = v;
+    }
+  if (p.do_f)
+    for (int e = tid; e < dm.JP * kTS; e += NT) {       // Q'[j][s] = x_k[s][d'] G'[g'][s],  j = d' * gp + g'
+      const int sl = e % kTS, j = e / kTS;
+      float v = 0.f;
+      if (j < nJ) {
+        const int dd = j >= gp ? 1 : 0;
+        v = sXk[sl * kD + dd] * (p.Gprev ? w.rGp[(j - dd * gp) * kTS + sl] : 1.0f);
+      }
+      w.sQp[j * kTSP + sl] = v;
+    }
+  if (p.do_ext)
+    for (int i = wave; i < dm.KA; i += NWV)
+      for (int o = lane; o < dm.HS; o += 64)
+        w.sA[i * dm.HS + o] = (i < nI && o < h) ? w.rA[i * h + o] : 0.f;
+  for (int e = tid; e < dm.J3 * kTS; e += NT) {         // Q[j][s] = x_{k+1}[s][dk1] G[g][s],  j = dk1 * g + g_
+    const int sl = e % kTS, j = e / kTS;
+    float v = 0.f;
+    if (j < kD * g) {
+      const int dd = j >= g ? 1 : 0;
+      v = sXp[sl * kD + dd] * (p.Gcur ? w.rG[(j - dd * g) * kTS + sl] : 1.0f);
+    }
+    w.sQ[j * kTSP + sl] = v;
+  }
+  __syncthreads();
+  if (p.do_ext) {                                       // H[hn][s] = sum_i A[i][hn] P'[i][s], all waves
+    const int HT = up(h, 16) / 16;
+    for (int cidx = wave; cidx < HT * ST; cidx += NWV) {
+      const int ht = cidx / ST, st = cidx % ST;
+      const float *ap = w.sA + q * dm.HS + ht * 16 + r;
+      const float *bq = w.sPp + q * kTSP + st * 16 + r;
+      fvec4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < dm.KA / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * dm.HS], bq[kk * 4 * kTSP], acc, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int hn = ht * 16 + 4 * q + reg;
+        w.sH[hn * kTSP + st * 16 + r] = acc[reg];
+        if (hn < h) p.Hcur[(size_t)hn * p.b_pad + s0 + st * 16 + r] = acc[reg];
+      }
+    }
+  }
+  __syncthreads();                                      // staging buffers and sA are dead: the chunk buffer takes over
+
+  // ---- phase B: f of the previous step, B' streamed in chunks of 16 rows ----------------------------------------
+  if (p.do_f) {
+    constexpr int kMaxCombo = 4;                        // (label, sample tile) pairs per wave: L * ST <= 32
+    float facc[kMaxCombo] = {0.f, 0.f, 0.f, 0.f};
+    const int rowlen = nJ * L;
+    for (int it = 0; it < dm.IP / 16; ++it) {
+      // rows it*16 .. +15 of B'[i][(j, l)] into the padded layout (row stride RS); tails and rows >= nI are zero
+      for (int rr = wave; rr < 16; rr += NWV) {
+        const int i = it * 16 + rr;
+        float *dst = w.sBc + rr * dm.RS;
+        if (i < nI) {
+          const float *src = p.Bprev + (size_t)i * rowlen;
+          for (int x0 = 0; x0 < rowlen; x0 += 64)
+            if (x0 + lane < rowlen) GLDS(src + x0 + lane, dst + x0);
+          for (int x = rowlen + lane; x < dm.RS; x += 64) dst[x] = 0.f;
+        } else {
+          for (int x = lane; x < dm.RS; x += 64) dst[x] = 0.f;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int cc = 0; cc < kMaxCombo; ++cc) {
+        const int cidx = wave + cc * NWV;
+        if (cidx >= L * ST) break;
+        const int l = cidx / ST, st = cidx % ST;
+        const float *bq = w.sQp + q * kTSP + st * 16 + r;
+        const float *ap = w.sBc + r * dm.RS + q * L + l;                    // B'[i][(j, l)], j = 4 kk + q
+        fvec4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 5
+        for (int kk = 0; kk < dm.JP / 4; ++kk)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * L], bq[kk * 4 * kTSP], acc, 0, 0, 0);
+        const float *pp = w.sPp + (it * 16 + 4 * q) * kTSP + st * 16 + r;
+        float fa = facc[cc];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) fa = fmaf(acc[reg], pp[reg * kTSP], fa);
+        facc[cc] = fa;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int cc = 0; cc < kMaxCombo; ++cc) {
+      const int cidx = wave + cc * NWV;
+      if (cidx >= L * ST) break;
+      const int l = cidx / ST, st = cidx % ST;
+      float fa = facc[cc];
+      fa += __shfl_xor(fa, 16);
+      fa += __shfl_xor(fa, 32);
+      if (q == 0) {
+        w.sF[l * kTS + st * 16 + r] = fa;
+        p.f[(size_t)l * p.b_pad + s0 + st * 16 + r] = fa;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- activation, metrics, loss derivative (one thread per sample) ------------------------------
+  {
+    __shared__ float sMet[3][kTS];
+    if (tid < kTS) {
+      const int s = s0 + tid;
+      float m_abs = 0.f;
+      int m_cor = 0, m_nf = 0;
+      if (s < p.b) {
+        act_and_lossder(w.sF + tid, kTS, w.sGl + tid, w.sGl + tid, kTS, L, p.y[s], p.act_fn, p.loss_fn, p.T, m_abs,
+                        m_cor, m_nf);
+      } else {
+        for (int l = 0; l < L; ++l) w.sGl[l * kTS + tid] = 0.f;
+      }
+      sMet[0][tid] = (float)m_cor; sMet[1][tid] = m_abs; sMet[2][tid] = (float)m_nf;
+    }
+    // P[i][s] = H[h][s] x_k[s][d] (the A operand of the gradient GEMM)
+    for (int e = tid; e < dm.I3 * kTS; e += NT) {
+      const int sl = e % kTS, i = e / kTS;
+      w.sP[i * kTSP + sl] = i < h * kD ? w.sH[(i >> 1) * kTSP + sl] * sXk[sl * kD + (i & 1)] : 0.f;
+    }
+    __syncthreads();
+    if (tid < 3) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < kTS; ++i) t += sMet[tid][i];
+      p.slabs[(size_t)blockIdx.x * p.slab_stride + p.bsize + tid] = t;
+    } else if (tid == 3) {
+      const int valid = p.b - s0;
+      p.slabs[(size_t)blockIdx.x * p.slab_stride + p.bsize + 3] = (float)(valid < 0 ? 0 : (valid > kTS ? kTS : valid));
+    }
+  }
+
+  // ---- partial bond gradient: dB[i, n] = sum_s P[i, s] (Q[j, s] g[l, s]),  n = j * L + l --------------------------
+  {
+    const int IT = dm.I3 / 16, QW = kD * g, NN = QW * L, NTL = (NN + 15) / 16;
+    float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride;
+    for (int cidx = wave; cidx < IT * NTL; cidx += NWV) {
+      const int it = cidx % IT, nt = cidx / IT;
+      const int n = nt * 16 + r;
+      const int nc = min(n, NN - 1);
+      const int j = nc / L, l = nc - j * L;
+      const float *ap = w.sP + (it * 16 + r) * kTSP + q;
+      const float *bq = w.sQ + j * kTSP + q;
+      const float *gq = w.sGl + l * kTS + q;
+      fvec4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < kTS / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4], bq[kk * 4] * gq[kk * 4], acc, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = it * 16 + 4 * q + reg;
+        if (i < h * kD && n < NN) slab[(size_t)i * NN + n] = acc[reg];
+      }
+    }
+  }
+#undef GLDS
+}
+
 static bool wide_use_mfma() {
   static const int v = [] { const char *e = getenv("TNML_WIDE"); return (e && e[0] == 'v' && e[1] == '1') ? 0 : 1; }();
   return v != 0;
@@ -705,6 +963,16 @@ bool launch_wide(const WideParams &p, int nblk, const PrepParams *prep, hipStrea
   if (wide_use_mfma()) {
     WideMfmaDims dm = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
     size_t lds = wide_mfma_carve(nullptr, dm, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
+    static const bool force_tiled = [] { const char *e = getenv("TNML_WIDE"); return e && std::string(e) == "tiled"; }();
+    if (lds > 160 * 1024 || force_tiled) {
+      // operands of a tile exceed LDS (or the tiled kernel is forced for tests): stream the merged tensor in chunks
+      WideMfmaDims dt = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
+      const size_t ldst = wide_tiled_carve(nullptr, dt, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
+      if (ldst <= 160 * 1024 && p.L * (kTS / 16) <= 4 * (kMfmaThreads / 64)) {
+        hipLaunchKernelGGL(wide_step_mfma_tiled_kernel, dim3(nblk), dim3(kMfmaThreads), ldst, st, p);
+        return false;
+      }
+    }
     if (lds <= 160 * 1024) {
       PrepParams q{};
       int extra = 0;

@@ -598,11 +598,11 @@ static int ensure_big(tnml_ctx *c) {
   const size_t rows_cols = (size_t)c->D * c->Mmax * (1 + c->L);
   HIP_TRY(hipMalloc(&c->big.Bf, c->bmax * sizeof(float)));
   HIP_TRY(hipMalloc(&c->big.T, c->bmax * sizeof(double)));
-  HIP_TRY(hipMalloc(&c->big.part, 3 * 128 * sizeof(double)));
-  HIP_TRY(hipMalloc(&c->big.gram, (size_t)kBigMaxN * kBigMaxN * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->big.part, 3 * kBigParts * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->big.gram, (size_t)8 * kBigMaxN * kBigMaxN * sizeof(double)));
   HIP_TRY(hipMalloc(&c->big.rotlog, ((size_t)30 * (kBigMaxN - 1) + 2) * (kBigMaxN / 2) * sizeof(double2)));
-  HIP_TRY(hipMalloc(&c->big.lam, kBigMaxN * sizeof(double)));
-  HIP_TRY(hipMalloc(&c->big.info, 4 * sizeof(int)));
+  HIP_TRY(hipMalloc(&c->big.lam, 3 * kBigMaxN * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->big.info, (4 + kBigMaxN) * sizeof(int)));
   HIP_TRY(hipMalloc(&c->big.VW, rows_cols * kBigMaxN * sizeof(double)));
   HIP_TRY(hipMalloc(&c->big.Cb, rows_cols * c->Mmax * sizeof(float)));
   HIP_TRY(hipMalloc(&c->big.T2, rows_cols * c->Mmax * sizeof(double)));

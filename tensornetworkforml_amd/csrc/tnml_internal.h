@@ -132,16 +132,17 @@ void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st);   /
 struct BigScratch {
   float *Bf;          // [bmax]   merged tensor
   double *T;          // [bmax]   Nh^T . B
-  double *part;       // [128][3] block-partial sums
-  double *gram;       // [128][128]
+  double *part;       // [kBigParts][3] block-partial sums
+  double *gram;       // [8][128][128] partial Gram matrices
   double2 *rotlog;    // [(kJacobiMaxSweeps * 127 + 2)][64] rotations (c, s) in application order
-  double *lam;        // [128]
-  int *info;          // rounds applied, sweeps, converged
+  double *lam;        // [3][128] eigenvalues by position, sigma^(1/2), sigma^(-1/2) of the kept columns
+  int *info;          // rounds applied, sweeps, converged, kept rank, then the eigenvalue order [128]
   double *VW;         // [(rows + cols)][n]  V, then W^T V
   float *Cb;          // [rows][m]  new behind core, contiguous
   double *T2;         // [rows][m]
 };
 constexpr int kBigMaxN = 128;
+constexpr int kBigParts = 512;
 size_t big_jacobi_lds_bytes(int n);
 void launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st);
 size_t narrow_lds_bytes(int h, int g, int s, int L, int m);

@@ -17,9 +17,8 @@ out = os.path.join(root, 'gpurun_out')
 
 
 def short(name):
-    name = re.sub(r'^void\s+', '', name)
-    name = re.sub(r'\(.*$', '', name)
-    return name.replace('tnml::', '').replace('(anonymous namespace)::', '')
+    name = re.sub(r'^void\s+', '', name).replace('(anonymous namespace)::', '').replace('tnml::', '')
+    return re.sub(r'\(.*$', '', name)
 
 
 stats = glob.glob(os.path.join(out, 'prof_kt_' + cfg, '**', '*kernel_stats.csv'), recursive=True)
