@@ -1,24 +1,27 @@
-// Single-workgroup kernels of the MPS sweep: everything that touches only the (small) merged
-// two-site tensor.  One launch per sweep step does
+// The batch-independent half of a sweep step, for merged two-site tensors that fit one workgroup's LDS
+// (kernels_big.hip is the HBM-resident variant).  One launch per sweep step does
 //   B = A_k . A_{k+1}                                   (Network_class.py:484)
 //   dB = dB_raw - 2 wd Ln.B.Rn   (or - wd B)            (:728-734, compute_L2_reg :966-1179)
 //   clip by the sum|.| ratio, B_new = B + lr dB         (:755-761)
 //   truncated SVD of the matricised B_new, sqrt(S) on both factors   (:528-563, :839-962)
 //   the two new cores, the behind norm environment of the next step, (accuracy, MAE)
-// all in LDS.  The update and the SVD run in float64: the norm environments of a 784-site chain
-// reach 1e196, and the SVD goes through the Gram matrix, whose float64 accumulation
-// keeps the squared condition number harmless for float32 data.
+// in workgroup 0's LDS.  On a single GPU the launch carries helper workgroups that sum the gradient slabs of
+// the wide kernel (and, when the wide launch did not do it, compute B and Ln.B.Rn slice by slice); workgroup 0
+// waits for their arrival counter.  The update and the SVD run in float64: the norm environments of a 784-site
+// chain reach 1e196, and the SVD goes through the Gram matrix, whose float64 accumulation keeps the
+// squared condition number harmless for float32 data.
 //
 // SVD method: G = W^T W (n x n, n = min(rows, cols) <= 64) accumulated in float64, then the classical
 // two-sided Jacobi eigenvalue iteration G <- J^T G J, V <- V J with a round-robin pair schedule:
-// n/2 disjoint rotations per round.  A thread owns one 2x2 block G[{p1,p2},{q1,q2}] (or V[{2r,2r+1},
-// {q1,q2}]) of the current pairing and applies both rotations to it, reading the old matrix and
-// writing the new one into a second LDS buffer, so a round costs one barrier and no reduction.  The
-// rotation angle comes from a float evaluation of t = 2g / (d + sign(d) sqrt(d^2 + 4 g^2)); c is
-// then refined to float64 (one Newton step on rsqrt) so that c^2 + s^2 = 1 to 1e-14 and V stays
-// orthogonal.  Eigenvalues sigma_j^2 = diag(G), eigenvectors q_j = columns of V.  The short-side
-// factor is q_j sqrt(sigma_j), the long-side one W q_j / sqrt(sigma_j), so that their product is the
-// projection W Q Q^T whatever the accuracy of the small sigma_j.
+// n/2 disjoint rotations per round, pairs always at positions (2k, 2k+1) ("position space").  A worker thread
+// owns one 2x2 block of the symmetric G (P <= Q) and applies both rotations to it, reading the old matrix and
+// writing the new one, already permuted for the next round, into a second LDS buffer; V lives in registers
+// (2x2 blocks, tournament move by DPP wave shifts); parameter threads prepare the next round's rotations
+// concurrently, so a round costs one barrier and no reduction.  The rotation angle comes from a float
+// evaluation of t = 2g / (d + sign(d) sqrt(d^2 + 4 g^2)); c is then refined to float64 (one Newton step on
+// rsqrt) so that c^2 + s^2 = 1 to 1e-14 and V stays orthogonal.  Eigenvalues sigma_j^2 = diag(G), eigenvectors
+// q_j = columns of V.  The short-side factor is q_j sqrt(sigma_j), the long-side one W q_j / sqrt(sigma_j), so
+// that their product is the projection W Q Q^T whatever the accuracy of the small sigma_j.
 #include "tnml_internal.h"
 #include "jacobi_device.h"
 #include "small_gemm_device.h"
@@ -589,9 +592,6 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
         cur ^= 1;
   };
   if (p.stamps && tid == 0) t_c1 = __builtin_amdgcn_s_memtime();
-#ifdef TNML_EXP_PRIO
-  if (tid < 64) __builtin_amdgcn_s_setprio(3);
-#endif
   if (n > 1) {
     kept2 = kept_scale(Gc);
     if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }

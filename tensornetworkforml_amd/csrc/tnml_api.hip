@@ -662,11 +662,6 @@ static int build_norm_chain(tnml_ctx *c, bool right_side) {
 // ---------------------------------------------------------------------------------------------
 // the sweep
 // ---------------------------------------------------------------------------------------------
-struct StepPlan {
-  int p, k, sb, sa, h, g, s, m;
-  WideParams w;
-  NarrowParams n;
-};
 
 static void prof_begin(tnml_ctx *c) { if (c->profile) (void)hipEventRecord(c->pev0, c->stream); }
 static void prof_end(tnml_ctx *c, int which) {
