@@ -235,7 +235,7 @@ def main():
         # runs of this command; gfx950 correction: FETCH_SIZE counts half of a coalesced read stream)
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_%s.json' % args.config)
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.policy == 'fixed' and not args.no_l2:
             w = json.load(open(pmc)).get(wide_name, {})
             if 'FETCH_SIZE' in w and 'WRITE_SIZE' in w:
                 traffic = (2.0 * w['FETCH_SIZE']['mean_KB'] + w['WRITE_SIZE']['mean_KB']) * 1024.0
@@ -243,7 +243,7 @@ def main():
         # event figure above brackets one isolated launch and carries its ~3 us of launch latency)
         rocprof_us = None
         kst = os.path.join(ROOT, 'profiles', 'r01_kernel_stats_%s.csv' % args.config)
-        if os.path.exists(kst):
+        if os.path.exists(kst) and args.policy == 'fixed' and not args.no_l2:     # the summary is of the default case
             import csv
             for row in csv.DictReader(open(kst)):
                 if wide_name + '(' in row['Name'] or row['Name'].split('(')[0].endswith(wide_name):
