@@ -439,7 +439,10 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   //   column pair Q = its lane within a group of np lanes) in registers; the column rotation is local and
   //   the tournament move (top element of pair Q -> pair Q+1, bottom element -> pair Q-1) is a one-lane
   //   wave shift (DPP wave_shr / wave_shl, tools/ubench/dpp_wave_shift.hip).
-  constexpr int kVR = 2;
+#ifndef TNML_KVR
+#define TNML_KVR 2
+#endif
+  constexpr int kVR = TNML_KVR;
   const int gpw = 64 / np;                               // groups of np lanes per V wave (np <= 32)
   const int NVW = (np + kVR * gpw - 1) / (kVR * gpw);    // V waves
   const int T0 = 64 * (1 + NVW);
@@ -776,16 +779,18 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   }
 #ifdef TNML_EXP_ROUND_TIMING
   // timing experiment (tools/build_exp.sh): ne-1 rounds each with parts of the round switched off, on the
-  // dead Jacobi buffers; cycles per round land in stamps[24..27]
+  // dead Jacobi buffers; cycles per round land in stamps[41..47]
   if (p.stamps && n > 2) {
     __syncthreads();
-    for (int variant = 0; variant < 4; ++variant) {
-      const bool xP = variant != 3, xG = variant == 0 || variant == 2 || variant == 3, xV = variant == 0 || variant == 1 || variant == 3;
+    for (int variant = 0; variant < 7; ++variant) {
+      // bit 0: parameter threads, bit 1: G items, bit 2: V blocks
+      const int mask = variant == 0 ? 7 : variant;          // 0 -> everything; 1 P; 2 G; 3 P+G; 4 V; 5 P+V; 6 G+V
+      const bool xP = mask & 1, xG = mask & 2, xV = mask & 4;
       __syncthreads();
       const unsigned long long e0 = __builtin_amdgcn_s_memtime();
       for (int rnd = 0; rnd < ne - 1; ++rnd) jacobi_round(false, xP, xG, xV);
       const unsigned long long e1 = __builtin_amdgcn_s_memtime();
-      if (tid == 0) p.stamps[24 + variant] = (double)(e1 - e0) / (double)(ne - 1);
+      if (tid == 0) p.stamps[41 + variant] = (double)(e1 - e0) / (double)(ne - 1);
     }
     if (vLaneOk) for (int r = 0; r < kVR; ++r) for (int q = 0; q < 4; ++q) V0[(vP0 + r) * 4 + q] += vb[r][q];   // keep V alive
   }

@@ -37,8 +37,8 @@ def stamp_line(tag, sc):
         print('   one round, parameter wave: loads+new elements %d / rotation %d / stores+barrier %d cycles' % tuple(sc[19:22]))
     if len(sc) > 28:
         print('   wide kernel WG0: x-stage %d / operand stage %d / f+env MFMA %d / activation %d / gP %d / dB MFMA+store %d cycles (own activation %d)' % tuple(sc[22:29]))
-    if len(sc) > 32 and sc[29] > 0:
-        print('   round-timing experiment (cycles per round): full %d / no G items %d / no V items %d / workers only %d' % tuple(sc[29:33]))
+    if len(sc) > 52 and sc[46] > 0:
+        print('   round-timing experiment (cycles per round): all %d | params only %d | G only %d | params+G %d | V only %d | params+V %d | G+V %d' % tuple(sc[46:53]))
     if len(sc) > 38 and sc[33] > 0:
         print('   fused launch, 10 ns ticks after workgroup 0 started: wait over %d | reduce helpers %d..%d | slice helpers %d..%d | polls %d' % tuple(sc[33:39]))
     if len(sc) > 45 and sc[39] > 0:
