@@ -57,4 +57,30 @@ template <int CTRL> __device__ inline double dpp_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// wave-wide maximum of a float without touching the LDS crossbar: xor-butterfly inside every 16-lane row by DPP
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row maxima by v_readlane
+__device__ inline float wave_max_f32(float v) {
+#define TNML_DPPMAX(ctrl)                                                                                         \
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), \
+                                                                       ctrl, 0xf, 0xf, false)))
+  TNML_DPPMAX(0xB1);
+  TNML_DPPMAX(0x4E);
+  TNML_DPPMAX(0x141);
+  TNML_DPPMAX(0x140);
+#undef TNML_DPPMAX
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// value of a double held by lane `src` (wave-uniform), by v_readlane
+__device__ inline double wave_read_f64(double v, int src) {
+  const int s_ = __builtin_amdgcn_readfirstlane(src);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), s_), hi = __builtin_amdgcn_readlane(__double2hiint(v), s_);
+  return __hiloint2double(hi, lo);
+}
+
 }  // namespace tnml

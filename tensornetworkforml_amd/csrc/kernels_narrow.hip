@@ -84,7 +84,7 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
   k.sCb = f; f += (size_t)r * m;
   int *ip = (int *)f;
   k.sOrd = ip; ip += ne;
-  k.sFlag = ip; ip += 4;
+  k.sFlag = ip; ip += 8;
   k.sPi = ip; ip += ne;
   k.sPiInv = ip; ip += ne;
   k.bytes = (size_t)((unsigned char *)ip - base);
@@ -424,9 +424,107 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   }
   const int sc_exp = (tr > 0.0 && isfinite(tr)) ? __builtin_amdgcn_frexp_exp(tr) : 0;
   __syncthreads();
-  for (int e = tid; e < ne * ne; e += NT) G0[e] = __builtin_amdgcn_ldexp(G0[e], -sc_exp);
-  __syncthreads();
+  double off2 = 0.0, dg2 = 0.0, dummy = 0.0;
+  for (int e = tid; e < ne * ne; e += NT) {
+    const double v = __builtin_amdgcn_ldexp(G0[e], -sc_exp);
+    G0[e] = v;
+    if (e / ne == e % ne) dg2 += v * v; else off2 += v * v;
+  }
+  block_sum3(off2, dg2, dummy, k.dRed);
 
+  // ---- phase 6b: one pivoted-Cholesky step when G is far from diagonal ------------------------------------------
+  // G = L L^T (diagonal pivoting), G' = L^T L has the same eigenvalues and is graded: the Jacobi iteration then needs
+  // 2-3 sweeps fewer on the merged tensors of the first training passes (off / trace >= 0.25) and the same number
+  // once the chain has settled (off / trace ~ 0.16), where the step is skipped (tools/jacobi_cholesky_emulation.py).
+  // Eigenvectors: G' u = lambda u  =>  G (L u) = lambda (L u), |L u|^2 = lambda.  No physical pivoting: column k
+  // of L is stored against the ORIGINAL row index (Lm[k][i] = L[i][k]), so G = L L^T and G' = L^T L hold as plain
+  // products.
+  double *Lm = k.Z + 3 * ne * ne;                          // free once the Gram partials are summed
+  const double trs = __builtin_amdgcn_ldexp(tr, -sc_exp);
+  const bool use_chol = p.chol_thr > 0.0 && n > 4 && off2 > p.chol_thr * p.chol_thr * trs * trs;
+  XSTAMP(5);
+  if (use_chol) {
+    for (int e = tid; e < ne * ne; e += NT) Lm[e] = 0.0;
+    // The factorisation is bound by LDS traffic, so a worker thread (waves 1..15) owns up to kCholPer fixed PAIRS of
+    // adjacent elements (i, 2jj), (i, 2jj+1) of the trailing matrix: one scalar and two 16-byte accesses per pair and
+    // step.  Lane i of wave 0 tracks diagonal entry i in a register instead, so the pivot search needs no LDS and
+    // runs while the other waves update.
+    constexpr int kCholPer = 3;                            // n <= 64: 2048 pairs on 960 threads
+    const int hn = n / 2, npairs = n * hn;
+    int ei[kCholPer], ej[kCholPer];
+#pragma unroll
+    for (int u = 0; u < kCholPer; ++u) {
+      const int pe = (tid - 64) + u * (NT - 64);
+      const bool ok = tid >= 64 && pe < npairs;
+      ei[u] = ok ? pe / hn : -1;
+      ej[u] = ok ? 2 * (pe - (pe / hn) * hn) : 0;
+    }
+    double dgi = (tid < n) ? G0[tid * ne + tid] : -1.0;   // wave 0: remaining diagonal entry of row `tid`, -1 once chosen
+    // pivot = largest remaining diagonal entry (a float key is enough to choose; lowest index on ties) and
+    // 1 / sqrt(pivot) by hardware float rsq + two Newton steps in float64.  Wave 0 searches the NEXT pivot while the
+    // other waves update the trailing matrix: results alternate between two flag slots.
+    auto pivot_search = [&](int slot) {
+      const float key = (float)dgi;
+      const float mx = wave_max_f32(key);
+      const unsigned long long hit = __ballot(key == mx);
+      const int jp = (mx > 1e-26f && hit) ? __ffsll((long long)hit) - 1 : -1;
+      const double piv = wave_read_f64(dgi, jp < 0 ? 0 : jp);
+      double inv0 = (double)__builtin_amdgcn_rsqf((float)piv);
+      inv0 = inv0 * fma(-0.5 * piv, inv0 * inv0, 1.5);
+      inv0 = inv0 * fma(-0.5 * piv, inv0 * inv0, 1.5);
+      if (tid == 0) { k.sFlag[4 + slot] = jp; k.dRed[61 + slot] = inv0; }
+    };
+    if (tid < 64) pivot_search(0);
+    for (int kc = 0; kc < n; ++kc) {
+      __syncthreads();                                     // A: pivot known; the previous update is complete
+      const int jp = k.sFlag[4 + (kc & 1)];
+      if (jp < 0) break;                                   // numerically rank deficient: the remaining columns stay zero
+      const double inv = k.dRed[61 + (kc & 1)];
+      double li[kCholPer];
+      double2 lj[kCholPer];
+#pragma unroll
+      for (int u = 0; u < kCholPer; ++u)                   // column jp of the trailing matrix, before anybody updates it
+        if (ei[u] >= 0) {                                  // (row jp == column jp: symmetric, conflict-free)
+          li[u] = G0[jp * ne + ei[u]] * inv;
+          const double2 c2 = *reinterpret_cast<const double2 *>(G0 + jp * ne + ej[u]);
+          lj[u] = make_double2(c2.x * inv, c2.y * inv);
+        }
+      if (tid < 64) {                                      // wave 0: column kc of L (original row index) and the diagonal
+        const double l = (tid < n && dgi >= 0.0) ? G0[jp * ne + tid] * inv : 0.0;
+        if (tid < n) Lm[kc * ne + tid] = l;                // L stored transposed: row kc = column kc of L
+        dgi = (tid == jp) ? -1.0 : (dgi >= 0.0 ? dgi - l * l : dgi);
+      }
+      __syncthreads();                                     // B: everybody holds its column values
+      if (tid < 64) {
+        if (kc + 1 < n) pivot_search((kc + 1) & 1);
+      } else {
+#pragma unroll
+        for (int u = 0; u < kCholPer; ++u)
+          if (ei[u] >= 0) {
+            double2 *g = reinterpret_cast<double2 *>(G0 + ei[u] * ne + ej[u]);
+            double2 v = *g;
+            v.x -= li[u] * lj[u].x;
+            v.y -= li[u] * lj[u].y;
+            *g = v;
+          }
+      }
+    }
+    __syncthreads();
+    XSTAMP(6);
+    // G' = L^T L into G0 (the trailing matrix is dead)
+    small_gemm_f64(1, n, n, n,
+                   [&](int, int a, int i) { return Lm[a * ne + i]; },
+                   [&](int, int i, int b) { return Lm[b * ne + i]; },
+                   [&](int, int a, int b, double v) { G0[a * ne + b] = v; });
+    __syncthreads();
+    for (int e = tid; e < n * n; e += NT) {                // exact symmetry
+      const int i = e / n, j = e - i * n;
+      if (i > j) G0[i * ne + j] = G0[j * ne + i];
+    }
+    __syncthreads();
+  }
+
+  XSTAMP(7);
   // ---- phase 7: two-sided Jacobi, ONE barrier per round ----------------------------------------------
   // Workers (tid >= 64) own one 2x2 block of G and one of V per item: rows by R_P^T, columns by R_Q,
   // written into the other buffer at the next round's positions.  Meanwhile parameter thread k
@@ -642,6 +740,18 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   // ---- phase 8: eigenvalues = diag(G), descending order -------------------------------------------
   for (int j = tid; j < n; j += NT) k.dLam[j] = __builtin_amdgcn_ldexp(fmax(Gc[j * ne + j], 0.0), sc_exp);
   __syncthreads();
+  if (use_chol) {
+    // back from the eigenvectors u of G' = L^T L to those of G: v = L u / sqrt(lambda) (columns stay at their positions)
+    small_gemm_f64(1, n, n, n,
+                   [&](int, int i, int kk) { return Lm[kk * ne + i]; },
+                   [&](int, int kk, int j) { return V[kk * ne + j]; },
+                   [&](int, int i, int j, double v) {
+                     const double ls = Gc[j * ne + j];
+                     Gn[i * ne + j] = ls > 1e-300 ? v / sqrt(ls) : 0.0;
+                   });
+    V = Gn;
+    __syncthreads();
+  }
   for (int j = tid >> 6; j < n; j += NT >> 6) {           // one wave per entry: lane i votes "i sorts before j" (n <= 64)
     const int i = tid & 63;
     const double lj = k.dLam[j];
@@ -765,6 +875,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
     p.stamps[34] = (double)(t_x[0] - t_p[2]); p.stamps[35] = (double)(t_x[1] - t_x[0]); p.stamps[36] = (double)(t_x[2] - t_x[1]);
     p.stamps[37] = (double)(t_p[3] - t_x[2]); p.stamps[38] = (double)(t_x[3] - t_p[3]); p.stamps[39] = (double)(t_x[4] - t_x[3]);
     p.stamps[40] = (double)(t_p[4] - t_x[4]);
+    p.stamps[48] = use_chol ? (double)(t_x[6] - t_x[5]) : 0.0; p.stamps[49] = use_chol ? (double)(t_x[7] - t_x[6]) : 0.0;
 #endif
     p.stamps[6] = (double)(t_c2b - t_c2); p.stamps[7] = (double)(t_c2c - t_c2b); p.stamps[8] = (double)(t_c3 - t_c2c);
   }

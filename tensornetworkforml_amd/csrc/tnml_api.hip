@@ -61,6 +61,7 @@ struct tnml_ctx {
   int last_bsize = 0, last_n = 0, last_h = 0, last_g = 0, last_left_dir = 0;
   bool debug = false, profile = false, stamps = false;
   double svd_stop2 = kSvdStop2Default;
+  double chol_thr = getenv("TNML_CHOL_THR") ? atof(getenv("TNML_CHOL_THR")) : kCholThrDefault;   // 0 disables the step
   double trunc_thr = 0.999;                  // adaptive truncation threshold (tensor_svd's default argument)
   double prof_ms[4] = {0, 0, 0, 0};
   long long prof_n[4] = {0, 0, 0, 0};
@@ -794,6 +795,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     n.dbg = (c->debug || mode == 1) ? c->dbg : nullptr;
     n.Bdirect = Bdirect_dev;
     n.svd_stop2 = c->svd_stop2;
+    n.chol_thr = c->chol_thr;
     n.stop_after_update = mode == 1;
     if (fused) {
       n.fused = 1; n.slabs = c->slabs; n.nslabs = nblk; n.slab_stride = c->slab_stride;
@@ -1058,6 +1060,7 @@ extern "C" int tnml_svd_split(tnml_ctx *c, const float *mat, int rows, int cols,
   n.dbg = c->dbg; n.status = c->status; n.counters = c->counters;
   n.Bdirect = c->Bscr;
   n.svd_stop2 = c->svd_stop2;
+  n.chol_thr = c->chol_thr;
   { int rc = run_narrow(c, n, npath); if (rc) return rc; }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(US, us_dev, (size_t)rows * m * sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -16,6 +16,7 @@ constexpr int kWideThreads = 1024; // 4 waves per SIMD: the v1 formulation is la
 constexpr int kNarrowThreads = 1024;
 constexpr int kMetricSlots = 4;    // per-slab tail: correct count, sum|y-fa|, non-finite count, pad
 constexpr int kDbgSigma = 128;     // capture block: 4 tensors, then this many singular values, then scalars
+constexpr double kCholThrDefault = 0.22;   // off(G)/trace(G) above which the Cholesky step pays off (kernels_narrow.hip phase 6b)
 constexpr double kSvdStop2Default = 1e-6;   // see jacobi_rot (jacobi_device.h) and tnml_set_svd_stop
 
 // A plain (label-free) core or the label core addressed in the sweep-relative frame.
@@ -99,6 +100,7 @@ struct NarrowParams {
   double trunc_thr;        // > 0: adaptive truncation threshold on cumsum(S) / sum(S); m is then the cap
   int left_dir;            // direction (only read when trunc_thr > 0: the output strides follow the kept rank)
   int *m_out;              // device int receiving the kept rank (adaptive truncation), may be nullptr
+  double chol_thr;         // > 0: one pivoted-Cholesky step before the Jacobi iteration when off(G) / trace(G) exceeds it
   double svd_stop2;        // Jacobi stops after a sweep whose rotations all had g^2 / scale^2 <= svd_stop2 (tnml_set_svd_stop)
   int *status;             // device status word: bit0 non-finite, bit1 jacobi not converged
 };

@@ -43,6 +43,8 @@ def stamp_line(tag, sc):
         print('   fused launch, 10 ns ticks after workgroup 0 started: wait over %d | reduce helpers %d..%d | slice helpers %d..%d | polls %d' % tuple(sc[33:39]))
     if len(sc) > 45 and sc[39] > 0:
         print('   fine stamps: phase-4 loop %d / block sums %d / update loop %d / barrier after update %d | zero fill+barrier %d / gram GEMM %d / symmetrise+tables %d' % tuple(sc[39:46]))
+    if len(sc) > 54 and sc[53] > 0:
+        print('   Cholesky step: factorisation %d / L^T L + symmetrise %d cycles' % (sc[53], sc[54]))
     if len(sc) > 13:
         print('   post split: sort %d / cores %d / norm env + metrics %d cycles' % (sc[11], sc[12], sc[13]))
 
