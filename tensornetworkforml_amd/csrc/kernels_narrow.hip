@@ -425,12 +425,14 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   const int sc_exp = (tr > 0.0 && isfinite(tr)) ? __builtin_amdgcn_frexp_exp(tr) : 0;
   __syncthreads();
   double off2 = 0.0, dg2 = 0.0, dummy = 0.0;
+  const bool chol_possible = p.chol_thr > 0.0 && n > 4;   // tiny matrices (chain ends, reference policy): not worth a reduction
   for (int e = tid; e < ne * ne; e += NT) {
     const double v = __builtin_amdgcn_ldexp(G0[e], -sc_exp);
     G0[e] = v;
     if (e / ne == e % ne) dg2 += v * v; else off2 += v * v;
   }
-  block_sum3(off2, dg2, dummy, k.dRed);
+  if (chol_possible) block_sum3(off2, dg2, dummy, k.dRed);
+  else __syncthreads();
 
   // ---- phase 6b: one pivoted-Cholesky step when G is far from diagonal ------------------------------------------
   // G = L L^T (diagonal pivoting), G' = L^T L has the same eigenvalues and is graded: the Jacobi iteration then needs
@@ -441,7 +443,11 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   // products.
   double *Lm = k.Z + 3 * ne * ne;                          // free once the Gram partials are summed
   const double trs = __builtin_amdgcn_ldexp(tr, -sc_exp);
-  const bool use_chol = p.chol_thr > 0.0 && n > 4 && off2 > p.chol_thr * p.chol_thr * trs * trs;
+  // threshold: measured break-even of the step against the sweeps it saves -- 0.22 for n >= 32 (C3: 8.1 k vs 7.8 k
+  // steps/s, cold start +8 %), 0.35 for smaller matrices whose sweeps are cheaper (C2, n = 20: 0.22 costs 17 %, 0.35 is
+  // neutral in the steady state and +2 % cold)
+  const double cthr = n >= 32 ? p.chol_thr : fmax(p.chol_thr, kCholThrSmall);
+  const bool use_chol = chol_possible && off2 > cthr * cthr * trs * trs;
   XSTAMP(5);
   if (use_chol) {
     for (int e = tid; e < ne * ne; e += NT) Lm[e] = 0.0;

@@ -16,6 +16,7 @@ constexpr int kWideThreads = 1024; // 4 waves per SIMD: the v1 formulation is la
 constexpr int kNarrowThreads = 1024;
 constexpr int kMetricSlots = 4;    // per-slab tail: correct count, sum|y-fa|, non-finite count, pad
 constexpr int kDbgSigma = 128;     // capture block: 4 tensors, then this many singular values, then scalars
+constexpr double kCholThrSmall = 0.35;     // the same for matrices with n < 32
 constexpr double kCholThrDefault = 0.22;   // off(G)/trace(G) above which the Cholesky step pays off (kernels_narrow.hip phase 6b)
 constexpr double kSvdStop2Default = 1e-6;   // see jacobi_rot (jacobi_device.h) and tnml_set_svd_stop
 
