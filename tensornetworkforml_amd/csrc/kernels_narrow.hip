@@ -543,10 +543,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   //   column pair Q = its lane within a group of np lanes) in registers; the column rotation is local and
   //   the tournament move (top element of pair Q -> pair Q+1, bottom element -> pair Q-1) is a one-lane
   //   wave shift (DPP wave_shr / wave_shl, tools/ubench/dpp_wave_shift.hip).
-#ifndef TNML_KVR
-#define TNML_KVR 2
-#endif
-  constexpr int kVR = TNML_KVR;
+  constexpr int kVR = 2;
   const int gpw = 64 / np;                               // groups of np lanes per V wave (np <= 32)
   const int NVW = (np + kVR * gpw - 1) / (kVR * gpw);    // V waves
   const int T0 = 64 * (1 + NVW);
@@ -718,11 +715,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
       // next round: any ne-1 consecutive rounds form a complete sweep
       const int any_rot = k.sFlag[0], big_rot = k.sFlag[1];
       __syncthreads();
-#ifdef TNML_EXP_FIXED_SWEEPS
-      if (sweeps + 1 >= TNML_EXP_FIXED_SWEEPS) { converged = 1; ++sweeps; break; }
-#else
       if (!any_rot || !big_rot) { converged = 1; ++sweeps; break; }
-#endif
       if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
       kept2 = kept_scale(Gc);
     }
