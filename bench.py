@@ -285,7 +285,14 @@ def main():
             ncpu = len(os.sched_getaffinity(0))
         except Exception:
             ncpu = os.cpu_count()
-        out['cpu_baseline'] = {'value': rate, 'unit': 'sweep-steps/s', 'cores': ncpu, 'kind': 'port',
+        blas_threads = None
+        try:                                   # threads NumPy's BLAS actually runs the einsum / matmul calls on
+            from threadpoolctl import threadpool_info
+            blas_threads = max([int(i.get('num_threads', 1)) for i in threadpool_info()] or [1])
+        except Exception:
+            pass
+        out['cpu_baseline'] = {'value': rate, 'unit': 'sweep-steps/s', 'cores': blas_threads or ncpu, 'host_cpus': ncpu,
+                               'kind': 'port',
                                'sample': 'float64 NumPy oracle (einsum/BLAS, cached norm environments): 1 forward on '
                                          'the full %d-sample batch (%.2f s) + %d sweep steps (%.1f ms each), '
                                          'extrapolated to a %d-step pass' % (b, t_fwd, args.cpu_steps, 1e3 * t_step, N - 1)}
