@@ -248,11 +248,21 @@ def main():
             for row in csv.DictReader(open(kst)):
                 if wide_name + '(' in row['Name'] or row['Name'].split('(')[0].endswith(wide_name):
                     rocprof_us = float(row['AverageNs']) / 1e3
-        out['roofline'] = {'bound': 'hbm', 'kernel': wide_name, 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                           'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                           'algorithmic_bytes_per_launch': bstep, 'kernel_avg_us_hip_events': wide_us,
-                           'kernel_avg_us_rocprofv3': rocprof_us,
-                           'whole_step_GBs': bstep * steps_per_s / 1e9}
+        flops_step = 4.0 * b * D * D * M * M * L + 2.0 * b * D * M * M      # dB GEMM + f GEMM + env extension
+        if args.config == 'c5':
+            # bond 50 / ten labels is the MFMA-bound case (580 flop per algorithmic byte); float32 MFMA peak of
+            # MI355X_MICROARCH.md: 157.3 TFLOP/s (v_mfma_f32_16x16x4_f32 runs at the float32 vector rate)
+            tf = flops_step / (wide_us * 1e-6) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': wide_name, 'achieved': tf, 'peak': 157.3, 'unit': 'TFLOP/s',
+                               'frac': tf / 157.3, 'traffic': None, 'algorithmic_flops_per_launch': flops_step,
+                               'algorithmic_bytes_per_launch': bstep, 'kernel_avg_us_hip_events': wide_us,
+                               'kernel_avg_us_rocprofv3': None}
+        else:
+            out['roofline'] = {'bound': 'hbm', 'kernel': wide_name, 'achieved': ach, 'peak': HBM_PEAK_GBS,
+                               'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
+                               'algorithmic_bytes_per_launch': bstep, 'kernel_avg_us_hip_events': wide_us,
+                               'kernel_avg_us_rocprofv3': rocprof_us,
+                               'whole_step_GBs': bstep * steps_per_s / 1e9}
     elif dist is not None and not args.no_kernel_profile:
         # keep the collectives of the profiling passes matched on every rank
         one_pass()
