@@ -336,3 +336,33 @@ def test_adaptive_truncation_vs_oracle(large):
         assert np.abs(met[:, 0] - np.array(vh[0])).max() <= 2.0 / b + 1e-6
     assert len(bonds_seen) > 2 and min(bonds_seen) < M      # the rank really adapts
     ctx.close()
+
+
+@pytest.mark.parametrize('N,M,b,L,policy', [(2, 2, 5, 2, 'fixed'), (2, 2, 5, 2, 'reference'), (3, 3, 1, 2, 'fixed'),
+                                            (4, 1, 3, 2, 'fixed'), (5, 2, 33, 3, 'fixed'), (3, 2, 7, 2, 'reference'),
+                                            (6, 4, 64, 2, 'adaptive')])
+def test_tiny_chains_and_batches(N, M, b, L, policy):
+    """Edge sizes: a two-site chain (the only step is first and last at once), one sample, bond 1, a batch that is
+    exactly / not a multiple of the 32-sample tile: two sweeps against the oracle."""
+    rng = np.random.default_rng(1)
+    D = 2
+    p = rng.random((b, N))
+    X = np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32)
+    y = rng.integers(0, L, b)
+    cores = [c.astype(np.float32) for c in mo.random_cores(N, M, D, L, rng=rng, scale=M * 0.64)]
+    st = mo.MPSState(N, D, L, M, [c.astype(np.float64) for c in cores])
+    ctx = make_ctx(N, D, L, M, cores, 0, X, y)
+    X64 = X.astype(np.float64)
+    for sw in range(2):
+        f_o = mo.forward(st, X64)
+        assert relerr(ctx.forward(), f_o) < 1e-4
+        left = st.l_pos == N - 1
+        vh = [[], []]
+        f_o = mo.sweep(st, X64, y, f_o, 1e-2, 1e-3, L2_flag=True, left_dir=left, var_hist=vh, act_fn='softmax',
+                       loss_fn='full_cross_ent', T=0.1, trunc=policy)
+        met, f_d = ctx.sweep(left, N - 1, True, 1e-2, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, policy)
+        assert relerr(f_d, f_o) < 1e-3
+        assert np.abs(met[:, 0] - np.array(vh[0])).max() < 1e-6
+        _, bond, lp = ctx.get_cores()
+        assert list(bond) == list(st.bond) and lp == st.l_pos
+    ctx.close()
