@@ -366,3 +366,27 @@ def test_tiny_chains_and_batches(N, M, b, L, policy):
         _, bond, lp = ctx.get_cores()
         assert list(bond) == list(st.bond) and lp == st.l_pos
     ctx.close()
+
+
+def test_batch_larger_than_the_capacity_given_at_creation():
+    """tnml_create's b_capacity is a hint: a larger batch re-allocates the batch-sized buffers (and a smaller one
+    afterwards must not see the old padding)."""
+    N, M, L, D = 10, 4, 2, 2
+    rng = np.random.default_rng(2)
+    cores = [c.astype(np.float32) for c in mo.random_cores(N, M, D, L, rng=rng, scale=M * 0.64)]
+    ctx = hip().Context(N, D, L, M, 16)
+    ctx.set_cores(cores, 0)
+    for b in (16, 300, 7):
+        p = rng.random((b, N))
+        X = np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32)
+        y = rng.integers(0, L, b)
+        ctx.set_input(X, y)
+        st = mo.MPSState(N, D, L, M, [c.astype(np.float64) for c in ctx.get_cores()[0]], ctx.l_pos)
+        f_o = mo.forward(st, X.astype(np.float64))
+        assert relerr(ctx.forward(), f_o) < 1e-4
+        left = st.l_pos == N - 1
+        f_o = mo.sweep(st, X.astype(np.float64), y, f_o, 1e-2, 1e-3, L2_flag=True, left_dir=left, act_fn='softmax',
+                       loss_fn='full_cross_ent', T=0.1, trunc='fixed')
+        _, f_d = ctx.sweep(left, N - 1, True, 1e-2, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
+        assert relerr(f_d, f_o) < 1e-3, b
+    ctx.close()
