@@ -492,25 +492,31 @@ __global__ __launch_bounds__(kBT) void big_cores_kernel(NarrowParams p, const do
 }
 
 // ---- behind norm environment of the next step: Nh_new = Cb^T (Nh (x) 1_d) Cb -----------------------------------
+// 16 lanes share one output element and split its inner sum (the outputs alone are too few to fill the chip);
+// the partial sums meet by xor shuffles inside the 16-lane group, in a fixed order
 __global__ __launch_bounds__(kBT) void big_norm_T_kernel(NarrowParams p, const float *__restrict__ Cb, double *__restrict__ T2,
                                                         const int *__restrict__ m_dev) {
   const int D = kD, h = p.h, m = m_dev[0], DM = D * m;
-  for (int e = blockIdx.x * kBT + threadIdx.x; e < h * DM; e += gridDim.x * kBT) {
+  const int sub = threadIdx.x & 15;
+  for (int e = (blockIdx.x * kBT + threadIdx.x) >> 4; e < h * DM; e += (gridDim.x * kBT) >> 4) {
     const int j = e % DM, i = e / DM;
     double acc = 0.0;
-    if (p.Nh) { for (int kk = 0; kk < h; ++kk) acc += p.Nh[i * h + kk] * (double)Cb[(size_t)kk * DM + j]; }
-    else acc = (double)Cb[e];
-    T2[e] = acc;
+    if (p.Nh) { for (int kk = sub; kk < h; kk += 16) acc += p.Nh[i * h + kk] * (double)Cb[(size_t)kk * DM + j]; }
+    else if (sub == 0) acc = (double)Cb[e];
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (sub == 0) T2[e] = acc;
   }
 }
 __global__ __launch_bounds__(kBT) void big_norm_out_kernel(NarrowParams p, const float *__restrict__ Cb, const double *__restrict__ T2,
                                                           const int *__restrict__ m_dev) {
   const int D = kD, h = p.h, m = m_dev[0];
-  for (int e = blockIdx.x * kBT + threadIdx.x; e < m * m; e += gridDim.x * kBT) {
+  const int sub = threadIdx.x & 15;
+  for (int e = (blockIdx.x * kBT + threadIdx.x) >> 4; e < m * m; e += (gridDim.x * kBT) >> 4) {
     const int j = e % m, i = e / m;
     double acc = 0.0;
-    for (int kk = 0; kk < h * D; ++kk) acc += (double)Cb[(size_t)kk * m + i] * T2[(size_t)kk * m + j];
-    p.Nh_new[e] = acc;
+    for (int kk = sub; kk < h * D; kk += 16) acc += (double)Cb[(size_t)kk * m + i] * T2[(size_t)kk * m + j];
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (sub == 0) p.Nh_new[e] = acc;
   }
 }
 
@@ -551,9 +557,10 @@ void launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   hipLaunchKernelGGL(big_cores_kernel, dim3(std::min(((n + len) * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, st, p, s.lam, s.info,
                      s.VW, s.Cb);
   if (p.Nh_new) {
-    const int nb2 = std::min((p.h * D * p.m + kBT - 1) / kBT, 256);
+    const int nb2 = std::min((16 * p.h * D * p.m + kBT - 1) / kBT, 1024);
     hipLaunchKernelGGL(big_norm_T_kernel, dim3(nb2), dim3(kBT), 0, st, p, s.Cb, s.T2, s.info + 3);
-    hipLaunchKernelGGL(big_norm_out_kernel, dim3(std::min((p.m * p.m + kBT - 1) / kBT, 256)), dim3(kBT), 0, st, p, s.Cb, s.T2, s.info + 3);
+    hipLaunchKernelGGL(big_norm_out_kernel, dim3(std::min((16 * p.m * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, st, p, s.Cb, s.T2,
+                       s.info + 3);
   }
 }
 
