@@ -16,11 +16,11 @@ constexpr int kJacobiMaxSweeps = 30;
 // diagonal entries far below the smallest eigenvalue that is KEPT are treated as if they were at
 // that level, i.e. the discarded cluster is not resolved to high relative accuracy (it only has to
 // be separated from the kept subspace).  Emulated on headline-shaped matrices: 7.5 sweeps instead
-// of 9.4, truncated product within 2e-8 of LAPACK's (tools/jacobi_emulation.py).
+// of 9.4, truncated product within 2e-8 of LAPACK's (tests/emulation/jacobi_emulation.py).
 constexpr double kJacobiTol2 = 1e-14;     // below: pair left alone
 // "big" rotation: g^2 / scale2 above NarrowParams::svd_stop2 (default kJacobiStop2).  A sweep without one ends
 // the iteration: quadratic convergence then leaves off-diagonals of relative size ~svd_stop2.  Measured on
-// the merged tensors of a C3-shaped run (tools/jacobi_correction_emulation.py, probe_svd_accuracy.py):
+// the merged tensors of a C3-shaped run (tests/emulation/jacobi_correction_emulation.py, probe_svd_accuracy.py):
 //   svd_stop2   sweeps (n = 40)   worst |A.C - best rank-m| / max|B|   worst relative error of a kept sigma
 //   1e-4        3.9               2e-4                                  5e-6
 //   1e-6        5.0               6e-6                                  7e-11

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   // ---- phase 6b: one pivoted-Cholesky step when G is far from diagonal ------------------------------------------
   // G = L L^T (diagonal pivoting), G' = L^T L has the same eigenvalues and is graded: the Jacobi iteration then needs
   // 2-3 sweeps fewer on the merged tensors of the first training passes (off / trace >= 0.25) and the same number
-  // once the chain has settled (off / trace ~ 0.16), where the step is skipped (tools/jacobi_cholesky_emulation.py).
+  // once the chain has settled (off / trace ~ 0.16), where the step is skipped (tests/emulation/jacobi_cholesky_emulation.py).
   // Eigenvectors: G' u = lambda u  =>  G (L u) = lambda (L u), |L u|^2 = lambda.  No physical pivoting: column k
   // of L is stored against the ORIGINAL row index (Lm[k][i] = L[i][k]), so G = L L^T and G' = L^T L hold as plain
   // products.

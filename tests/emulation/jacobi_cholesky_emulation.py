@@ -1,7 +1,10 @@
 """CPU emulation: one pivoted-Cholesky step (G = L L^T, G' = L^T L) before the Jacobi iteration -- sweeps saved per training
 pass and their relation to off(G)/trace(G), which the kernel uses to decide whether to take the step."""
+import os as _os, sys as _sys
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+_sys.path.insert(0, _HERE); _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_HERE)))
+
 import sys, numpy as np
-sys.path.insert(0,'/root/repo/tools'); sys.path.insert(0,'/root/repo')
 import jacobi_warm_start_emulation as J
 from oracle import mps_oracle as mo
 def pchol(G):

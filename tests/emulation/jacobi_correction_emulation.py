@@ -2,9 +2,12 @@
 After the last sweep (all rotations small) the rotated Gram matrix G' = V^T G V has off-diagonals of
 relative size ~1e-4.  V <- V (I + X), X_ij = g_ij / (g_jj - g_ii) removes them to second order for one GEMM
 instead of one more sweep.  Evaluated on the matrices a device run produced (gpurun_out/svd_mats_*.npz)."""
+import os as _os, sys as _sys
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+_sys.path.insert(0, _HERE); _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_HERE)))
+
 import sys
 import numpy as np
-sys.path.insert(0, '/root/repo/tools')
 import jacobi_warm_start_emulation as J
 
 
@@ -45,7 +48,7 @@ def evaluate(W, m, big2, do_corr):
 if __name__ == '__main__':
     rows = []
     for side in ('right', 'left'):
-        d = np.load('/root/repo/gpurun_out/svd_mats_%s.npz' % side)
+        d = np.load(_os.path.join(_os.path.dirname(_os.path.dirname(_HERE)), 'gpurun_out', 'svd_mats_%s.npz' % side))
         for i, m in enumerate(d['m']):
             Bm = d['B%d' % i].astype(np.float64)
             W = Bm if Bm.shape[0] <= Bm.shape[1] else Bm.T

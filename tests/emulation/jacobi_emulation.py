@@ -1,5 +1,7 @@
+import os as _os, sys as _sys
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+_sys.path.insert(0, _HERE); _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_HERE)))
 import numpy as np, sys
-sys.path.insert(0,'/root/repo')
 from oracle import mps_oracle as mo
 
 def make_mats(N=24,M=20,b=1500,L=2,seed=0):

@@ -1,3 +1,6 @@
+import os as _os, sys as _sys
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+_sys.path.insert(0, _HERE); _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_HERE)))
 import numpy as np
 from jacobi_emulation import make_mats, pi_perm
 def jacobi_m(G, W, m, tol2=1e-14, big2=1e-6, frac=0.05, maxs=20):

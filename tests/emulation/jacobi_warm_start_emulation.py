@@ -1,9 +1,12 @@
 """CPU emulation: how many Jacobi sweeps does the step's SVD need if the Gram matrix is first rotated
 by the eigenvectors found at the same (site, direction) one pass-pair earlier?  The oracle's SVD is
 replaced by the emulated Jacobi so that the bond gauges are the ones the device would produce."""
+import os as _os, sys as _sys
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+_sys.path.insert(0, _HERE); _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_HERE)))
+
 import sys
 import numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
 from oracle import mps_oracle as mo
 from jacobi_emulation import pi_perm
 
