@@ -94,6 +94,8 @@ def main():
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--svd-stop', type=float, default=None, help='Jacobi stopping threshold (tnml_set_svd_stop); default: the library default')
     ap.add_argument('--no-cold', action='store_true', help='skip the re-initialised (cold start) passes')
+    ap.add_argument('--sync-interval', type=int, default=0, help='drain the stream every so many sweep steps (runs under rocprofv3 --pmc)')
+    ap.add_argument('--check-launches', action='store_true', help='read the launch status back after every kernel launch')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -115,6 +117,10 @@ def main():
     if args.svd_stop is not None:
         ctx.set_svd_stop(args.svd_stop)
     tdist.attach_comm(ctx, rank, world)
+    if args.sync_interval:
+        ctx.set_sync_interval(args.sync_interval)
+    if args.check_launches:
+        ctx.debug_enable(4)
 
     X, y = synth(N, b, L, 1234 + rank)          # every rank owns a different shard
     cores = init_cores(N, M, D, L, 99)            # same cores on every rank

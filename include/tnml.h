@@ -155,6 +155,11 @@ int tnml_predict(tnml_ctx *ctx, const float *X, int b, float *f_out);
  * 1e-8 costs one more and reaches ~1e-6.  Allowed range [1e-12, 1e-2]. */
 int tnml_set_svd_stop(tnml_ctx *ctx, double stop2);
 
+/* tnml_sweep enqueues every launch of its n_steps steps without waiting (2 - 14 launches per step).  A profiler that
+ * intercepts dispatches (rocprofv3 --pmc serialises them and keeps per-dispatch state) can be overrun by tens of
+ * thousands of queued launches; n_steps > 0 drains the stream every n_steps steps, 0 (default) never. */
+int tnml_set_sync_interval(tnml_ctx *ctx, int n_steps);
+
 /* The batch-independent part of a step (update_B's tail, compute_L2_reg, tensor_svd) runs in one
  * workgroup's LDS when the merged tensor fits (min(rows, cols) <= 64 and <= 160 KB of LDS: bond <= 32 at
  * two labels) and through HBM-resident kernels otherwise (min(rows, cols) <= 128: bond 50 with ten labels).
@@ -176,7 +181,9 @@ int tnml_activation(tnml_ctx *ctx, int act_fn, int loss_fn, float T, int input_i
 
 /* ---- inspection (API parity: Network.r_cum_contraction / l_cum_contraction) -------------- */
 int tnml_get_env(tnml_ctx *ctx, int side, int site, float *out, size_t capacity, int *m);
-/* capture B, dB, B_new, sigma of every step into a debug block (tests only; off by default) */
+/* bit 0: capture B, dB, B_new, sigma of every step into a debug block (tests only; off by default);
+ * bit 1: in-kernel cycle stamps only; bit 2: read the launch status back after every kernel launch of a step
+ * (a failed launch then names its kernel; launch geometry is validated before every launch regardless) */
 int tnml_debug_enable(tnml_ctx *ctx, int on);
 int tnml_get_step_debug(tnml_ctx *ctx, int what, double *out, size_t capacity, size_t *n);
 int tnml_l_pos(tnml_ctx *ctx);

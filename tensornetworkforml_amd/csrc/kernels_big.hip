@@ -12,6 +12,7 @@
 //
 // Reference lines: update_B Network_class.py:577-763, compute_L2_reg :966-1179, tensor_svd :839-962.
 #include <algorithm>
+#include <cstdio>
 
 #include "tnml_internal.h"
 #include "jacobi_device.h"
@@ -528,40 +529,76 @@ size_t big_jacobi_lds_bytes(int n) {
   return (8 * nblk + 8 * (size_t)np + 64) * sizeof(double) + (2 * (size_t)n + 8) * sizeof(int) + 16;
 }
 
-void launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st) {
+// Every launch of this path goes through big_launch: grid, block and dynamic-LDS sizes are validated against the
+// device limits BEFORE the launch (an illegal AQL packet aborts the queue, it does not return an error), and in
+// checking mode (tnml_debug_enable bit 2) the launch status is read back after each one, so that a failure names its kernel.
+static thread_local char g_big_err[256];
+const char *big_launch_error() { return g_big_err; }
+
+template <class K, class... Args>
+static bool big_launch(const char *name, bool check, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+  const unsigned long long nthreads = (unsigned long long)block.x * block.y * block.z;
+  if (grid.x < 1 || grid.y < 1 || grid.z < 1 || grid.x > 0x7fffffffu || grid.y > 65535u || grid.z > 65535u ||
+      nthreads < 1 || nthreads > 1024 || lds > 160 * 1024) {
+    snprintf(g_big_err, sizeof g_big_err, "%s: illegal launch grid (%u,%u,%u) block (%u,%u,%u) dynamic LDS %zu", name, grid.x,
+             grid.y, grid.z, block.x, block.y, block.z, lds);
+    return false;
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  if (check) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      snprintf(g_big_err, sizeof g_big_err, "%s: launch failed: %s (grid %u,%u,%u block %u lds %zu)", name, hipGetErrorString(e),
+               grid.x, grid.y, grid.z, block.x, lds);
+      return false;
+    }
+  }
+  return true;
+}
+
+bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check) {
   const int D = kD, Bs = p.bsize;
   const int r = D * p.h, c = D * p.g * p.L;
   const bool short_rows = r <= c;
   const int n = short_rows ? r : c, len = short_rows ? c : r;
   const int si = short_rows ? c : 1, sx = short_rows ? 1 : c;
+  if (n < 2 || n > kBigMaxN || (n & 1) || p.m < 1 || p.m > n || Bs < 1) {
+    snprintf(g_big_err, sizeof g_big_err, "large-tensor path: unsupported matrix %d x %d, kept rank %d", r, c, p.m);
+    return false;
+  }
   const int nbe = std::min((Bs + kBT - 1) / kBT, 2048);          // one element per thread
   const int nb = std::min((Bs + kBT - 1) / kBT, kBigParts);      // kernels that leave block partials
   const float *Bf = p.Bdirect;
+#define BIG(kern, grid, block, lds, ...) \
+  if (!big_launch(#kern, check, kern, grid, block, lds, st, __VA_ARGS__)) return false
   if (!Bf) {
-    hipLaunchKernelGGL(big_merge_kernel, dim3(nbe), dim3(kBT), 0, st, p, s.Bf);
+    BIG(big_merge_kernel, dim3(nbe), dim3(kBT), 0, p, s.Bf);
     Bf = s.Bf;
   }
   double *ws = p.dbg;                          // the capture block doubles as the workspace of this path
-  if (p.l2_flag) hipLaunchKernelGGL(big_l2_T_kernel, dim3(nbe), dim3(kBT), 0, st, p, Bf, s.T);
-  hipLaunchKernelGGL(big_wd_kernel, dim3(nb), dim3(kBT), 0, st, p, Bf, s.T, ws, s.part);
-  hipLaunchKernelGGL(big_update_kernel, dim3(nb), dim3(kBT), 0, st, p, ws, s.part, nb);
-  if (p.stop_after_update) return;
+  if (p.l2_flag) BIG(big_l2_T_kernel, dim3(nbe), dim3(kBT), 0, p, Bf, s.T);
+  BIG(big_wd_kernel, dim3(nb), dim3(kBT), 0, p, Bf, (const double *)s.T, ws, s.part);
+  BIG(big_update_kernel, dim3(nb), dim3(kBT), 0, p, ws, (const double *)s.part, nb);
+  if (p.stop_after_update) return true;
   const int nt = (n + 15) / 16;
-  hipLaunchKernelGGL(big_gram_kernel, dim3(nt, nt, kGramKS), dim3(256), 0, st, p.Bnew, n, len, si, sx, s.gram);
+  BIG(big_gram_kernel, dim3(nt, nt, kGramKS), dim3(256), 0, (const float *)p.Bnew, n, len, si, sx, s.gram);
   BigJacobiArgs a{};
   a.G = s.gram; a.n = n; a.m = p.m; a.stop2 = p.svd_stop2; a.rotlog = s.rotlog; a.lam = s.lam; a.info = s.info;
   a.counters = p.counters; a.status = p.status;
-  hipLaunchKernelGGL(big_jacobi_kernel, dim3(1), dim3(1024), big_jacobi_lds_bytes(n), st, a);
-  hipLaunchKernelGGL(big_replay_kernel, dim3(n + len), dim3(64), 0, st, p.Bnew, n, len, si, sx, s.rotlog, s.info, s.VW);
-  hipLaunchKernelGGL(big_order_kernel, dim3(1), dim3(128), 0, st, p, s.lam, s.info, ws);
-  hipLaunchKernelGGL(big_cores_kernel, dim3(std::min(((n + len) * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, st, p, s.lam, s.info,
-                     s.VW, s.Cb);
+  BIG(big_jacobi_kernel, dim3(1), dim3(1024), big_jacobi_lds_bytes(n), a);
+  BIG(big_replay_kernel, dim3(n + len), dim3(64), 0, (const float *)p.Bnew, n, len, si, sx, (const double2 *)s.rotlog,
+      (const int *)s.info, s.VW);
+  BIG(big_order_kernel, dim3(1), dim3(128), 0, p, s.lam, s.info, ws);
+  BIG(big_cores_kernel, dim3(std::min(((n + len) * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, p, (const double *)s.lam,
+      (const int *)s.info, (const double *)s.VW, s.Cb);
   if (p.Nh_new) {
     const int nb2 = std::min((16 * p.h * D * p.m + kBT - 1) / kBT, 1024);
-    hipLaunchKernelGGL(big_norm_T_kernel, dim3(nb2), dim3(kBT), 0, st, p, s.Cb, s.T2, s.info + 3);
-    hipLaunchKernelGGL(big_norm_out_kernel, dim3(std::min((16 * p.m * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, st, p, s.Cb, s.T2,
-                       s.info + 3);
+    BIG(big_norm_T_kernel, dim3(nb2), dim3(kBT), 0, p, (const float *)s.Cb, s.T2, (const int *)(s.info + 3));
+    BIG(big_norm_out_kernel, dim3(std::min((16 * p.m * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, p, (const float *)s.Cb,
+        (const double *)s.T2, (const int *)(s.info + 3));
   }
+#undef BIG
+  return true;
 }
 
 }  // namespace tnml

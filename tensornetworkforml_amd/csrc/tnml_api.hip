@@ -60,6 +60,8 @@ struct tnml_ctx {
   int prev_left_dir = 0, prev_p = -1;
   int last_bsize = 0, last_n = 0, last_h = 0, last_g = 0, last_left_dir = 0;
   bool debug = false, profile = false, stamps = false;
+  bool check_launches = false;               // tnml_debug_enable bit 2: read the launch status back after every kernel launch
+  int sync_interval = 0;                     // tnml_set_sync_interval: drain the stream every so many steps (0 = never)
   double svd_stop2 = kSvdStop2Default;
   double chol_thr = getenv("TNML_CHOL_THR") ? atof(getenv("TNML_CHOL_THR")) : kCholThrDefault;   // 0 disables the step
   double trunc_thr = 0.999;                  // adaptive truncation threshold (tensor_svd's default argument)
@@ -632,7 +634,7 @@ static int run_narrow(tnml_ctx *c, NarrowParams &n, int path) {
   int rc = ensure_big(c);
   if (rc) return rc;
   n.dbg = c->dbg;                       // the capture block is this path's workspace
-  launch_narrow_big(n, c->big, c->stream);
+  if (!launch_narrow_big(n, c->big, c->stream, c->check_launches)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
   return TNML_OK;
 }
 
@@ -889,6 +891,8 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     c->Bnew_valid = true;
     c->f_current = false;
     c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
+    if (c->check_launches) HIP_TRY(hipGetLastError());
+    if (c->sync_interval > 0 && (step + 1) % c->sync_interval == 0) HIP_TRY(hipStreamSynchronize(c->stream));
   }
   HIP_TRY(hipGetLastError());
   // the sweep grew the behind stacks: they are the ones valid for the opposite direction now
@@ -1115,6 +1119,13 @@ extern "C" int tnml_set_narrow_path(tnml_ctx *c, int force_large) {
   return TNML_OK;
 }
 
+extern "C" int tnml_set_sync_interval(tnml_ctx *c, int n_steps) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  if (n_steps < 0) return fail(TNML_ERR_ARG, "negative interval");
+  c->sync_interval = n_steps;
+  return TNML_OK;
+}
+
 extern "C" int tnml_set_svd_stop(tnml_ctx *c, double stop2) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   if (!(stop2 >= 1e-12 && stop2 <= 1e-2)) return fail(TNML_ERR_ARG, "svd stop threshold %g outside [1e-12, 1e-2]", stop2);
@@ -1126,6 +1137,7 @@ extern "C" int tnml_debug_enable(tnml_ctx *c, int on) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   c->debug = (on & 1) != 0;    // 1: full capture of every step
   c->stamps = (on & 2) != 0;   // 2: cycle stamps only (timing runs)
+  c->check_launches = (on & 4) != 0;   // 4: launch status read back after every launch of a step
   return TNML_OK;
 }
 

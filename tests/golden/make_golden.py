@@ -224,6 +224,62 @@ def trajectory(name, cls, N, M, L, b, act_fn, loss_fn, lr, wd, L2_flag, n_sweeps
     print('wrote', name, 'steps', step)
 
 
+def light_trajectory(name, cls, N, M, L, b, act_fn, loss_fn, lr, wd, L2_flag, n_sweeps, seed, policy, T=0.1,
+                     x_zero_frac=0.0):
+    """Free-running sweeps of the reference at a large bond dimension: inputs, initial cores and, per step, only the
+    small gauge-invariant outputs (f, metrics, singular values, L2 loss, bonds).  The merged tensors of these shapes
+    (100 x 1000 at M = 50, L = 10) would make the fixture tens of MB; the oracle is held to them element-wise on the
+    small trajectories, here the point is the reference's arithmetic at the bench's bond dimensions."""
+    rng = np.random.default_rng(seed)
+    p = rng.random((b, N))
+    if x_zero_frac:
+        p = p * (rng.random((b, N)) > x_zero_frac)
+    X = psi(p)
+    y = rng.integers(0, L, b)
+    net = make_net(cls, N, M, L, X, act_fn, loss_fn, seed, T)
+    out = dict(N=N, M=M, L=L, D=2, b=b, T=T, lr=lr, wd=wd, L2_flag=L2_flag, n_sweeps=n_sweeps, act_fn=act_fn,
+               loss_fn=loss_fn, policy=policy, X=X, y=y, numpy_version=np.__version__)
+    for i, c in enumerate(canon_cores(net)):
+        out['init_core%d' % i] = c
+    rec = Recorder(net)
+    step = 0
+    for sw in range(n_sweeps):
+        with quiet():
+            f = net.forward(X)
+        left_dir = (net.l_pos == N - 1)
+        out['sw%d_left_dir' % sw] = left_dir
+        out['sw%d_f_forward' % sw] = f_lb(f)
+        one_hot = np.zeros((y.size, L))
+        one_hot[np.arange(y.size), y] = 1
+        yT = one_hot.T
+        if left_dir:
+            net.r_cum_contraction = []
+        else:
+            net.l_cum_contraction = []
+        for _ in range(N - 1):
+            pre = 'st%d_' % step
+            vh = [[], []]
+            rec.rec = {}
+            with quiet():
+                f = net.sweep_step(f, yT, lr, b, wd, L2_flag=L2_flag, left_dir=left_dir, var_hist=vh)
+            out[pre + 'f_new'] = f_lb(f)
+            out[pre + 'accuracy'] = vh[0][0]
+            out[pre + 'MAE'] = vh[1][0]
+            out[pre + 'S'] = rec.rec['S']
+            if L2_flag:
+                out[pre + 'L2_loss'] = rec.rec['L2_loss']
+            out[pre + 'absB_new'] = np.abs(rec.rec['B_new']).sum()
+            out[pre + 'bond'] = np.array([core_from_named(A.elem, A.axes_names, i, N).shape[2]
+                                          for i, A in enumerate(net.As)][:-1])
+            step += 1
+    out['n_steps'] = step
+    out['final_l_pos'] = net.l_pos
+    with quiet():
+        out['final_f'] = f_lb(net.forward(X))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, 'steps', step)
+
+
 def forward_fixture(name, N, M, L, b, seed):
     """forward at l_pos = 0 and (after a fixed-bond right sweep) at l_pos = N-1."""
     rng = np.random.default_rng(seed)
@@ -334,12 +390,25 @@ def shipped_model_fixture():
     print('wrote shipped_diag_model, accuracy', out['accuracy'])
 
 
+def main_light():
+    light_trajectory('ltraj_fixed_M20', FixedBondNetwork, N=12, M=20, L=2, b=64, act_fn='softmax',
+                     loss_fn='full_cross_ent', lr=1e-3, wd=1e-3, L2_flag=True, n_sweeps=2, seed=106, policy='fixed',
+                     x_zero_frac=0.5)
+    light_trajectory('ltraj_fixed_M10', FixedBondNetwork, N=14, M=10, L=2, b=40, act_fn='softmax',
+                     loss_fn='full_cross_ent', lr=1e-3, wd=1e-3, L2_flag=True, n_sweeps=2, seed=108, policy='fixed',
+                     x_zero_frac=0.5)
+    light_trajectory('ltraj_fixed_M50_L10', FixedBondNetwork, N=14, M=50, L=10, b=40, act_fn='softmax',
+                     loss_fn='full_cross_ent', lr=1e-3, wd=1e-3, L2_flag=True, n_sweeps=2, seed=107, policy='fixed')
+
+
 COMBOS = [('softmax', 'full_cross_ent'), ('linear', 'MSE'), ('sigmoid', 'MSE'), ('softmax', 'MSE'),
           ('softmax', 'cross_entropy'), ('sigmoid', 'cross_entropy'), ('linear', 'cross_entropy'),
           ('sigmoid', 'full_cross_ent'), ('linear', 'full_cross_ent')]
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'light':
+        return main_light()
     contract_fixture()
     forward_fixture('forward_N6_M2', 6, 2, 2, 7, 1)
     forward_fixture('forward_N16_M4', 16, 4, 2, 32, 2)
@@ -369,6 +438,7 @@ def main():
     trajectory('traj_fixed_L10', FixedBondNetwork, N=8, M=6, L=10, b=24, act_fn='softmax',
                loss_fn='full_cross_ent', lr=0.05, wd=0.01, L2_flag=True, n_sweeps=2, seed=105,
                policy='fixed')
+    main_light()     # the bench's bond dimensions on short chains (small outputs only)
     shipped_model_fixture()
 
 

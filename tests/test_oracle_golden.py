@@ -112,6 +112,41 @@ def test_free_running_trajectory(name):
     close(mo.forward(st, d['X']), d['final_f'], rtol=1e-6)
 
 
+@pytest.mark.parametrize('name', gu.names('ltraj_'))
+def test_free_running_large_bond(name):
+    """The bench's bond dimensions (20 with two labels, 50 with ten, 10) on short chains: the reference with only
+    tensor_svd's truncation overridden stored f, metrics, singular values, L2 loss and bonds of every step; the
+    oracle reproduces them free-running from the initial cores."""
+    d = gu.load(name)
+    N, M, L, D = int(d['N']), int(d['M']), int(d['L']), int(d['D'])
+    kw = _step_kwargs(d)
+    y1h = mo.one_hot(d['y'], L)
+    st = mo.MPSState(N, D, L, M, gu.indexed(d, 'init_core', N), 0)
+    k = 0
+    for sw in range(int(d['n_sweeps'])):
+        f = mo.forward(st, d['X'])
+        close(f, d['sw%d_f_forward' % sw], rtol=1e-7)
+        left_dir = bool(d['sw%d_left_dir' % sw])
+        if left_dir:
+            st.Renv = {}
+        else:
+            st.Lenv = {}
+        for j in range(N - 1):
+            rec = {}
+            f = mo.sweep_step(st, f, y1h, left_dir=left_dir, record=rec, **kw)
+            pre = 'st%d_' % k
+            close(f, d[pre + 'f_new'], rtol=1e-6)
+            close(rec['S'], d[pre + 'S'], rtol=1e-7)
+            close(rec['L2_loss'], d[pre + 'L2_loss'], rtol=1e-7)
+            close(np.abs(rec['B_new']).sum(), d[pre + 'absB_new'], rtol=1e-8)
+            assert abs(rec['accuracy'] - float(d[pre + 'accuracy'])) < 1e-12
+            assert abs(rec['MAE'] - float(d[pre + 'MAE'])) < 1e-8
+            assert list(st.bond) == [int(x) for x in d[pre + 'bond']]
+            k += 1
+    assert max(st.bond) == min(M, max(st.bond)) and M in st.bond     # the bond dimension under test is really reached
+    close(mo.forward(st, d['X']), d['final_f'], rtol=1e-6)
+
+
 def test_reference_policy_crashes_for_L3():
     """The unmodified reference raises at the last right step when D*L > D*left
     (Network_class.py:914); the oracle mirrors it with ValueError under trunc='reference'."""

@@ -1,0 +1,325 @@
+"""GPU parity at the shapes bench.py times (BASELINE.json configs C2, C3, C5) and accuracy parity of whole
+trainings, all through the C ABI of include/tnml.h against the float64 oracle on the same inputs.
+
+  * reference-generated fixed-policy trajectories at bond 10 / 20 (two labels) and bond 50 with ten labels
+    (tests/golden/ltraj_*.npz): device f, singular values, metrics and bonds of every step;
+  * C3 (N = 784, bond 20, batch 5000) and C2 (N = 784, bond 10, batch 1000) at their true shape: forward + one
+    right sweep + forward + one left sweep (783 steps each) against `mo.sweep`, the network function on fresh
+    inputs afterwards;
+  * C5's true matrix shape (bond 50, ten labels, batch 5000: a 100 x 1000 merged tensor, n = 100 Jacobi, the tiled
+    wide kernel over 157 sample tiles) on a 24-site chain, step by step: singular values, f, and the product of the
+    two new cores against LAPACK's best rank-m approximation of the device's own updated tensor;
+  * end accuracy of a diagonals training (the only task the reference learns, training_diagonals.py:33-65) and of
+    four sweeps on MNIST-shaped synthetic data, device vs oracle from the same seed and batches, within 0.5 %.
+
+Tolerances (float32 device vs float64 oracle) are stated at each assert with the value observed on MI355X.
+"""
+import contextlib
+import io
+import time
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import mps_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+HP = dict(lr=1e-3, weight_dec=1e-3, L2_flag=True, act_fn='softmax', loss_fn='full_cross_ent', T=0.1)
+
+
+def hip():
+    from tensornetworkforml_amd import _hip
+    return _hip
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def synth(N, b, L, seed, zero_frac=0.81):
+    """bench.py's synthetic MNIST-shaped input."""
+    rng = np.random.default_rng(seed)
+    p = rng.random((b, N), dtype=np.float32) * (rng.random((b, N), dtype=np.float32) > zero_frac)
+    X = np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32)
+    y = rng.integers(0, L, b).astype(np.int32)
+    return X, y
+
+
+def calibrated_pair(N, M, D, L, X, seed):
+    """Oracle state and device cores starting from the same float32-rounded, calibrated numbers."""
+    rng = np.random.default_rng(seed)
+    st = mo.MPSState(N, D, L, M, mo.random_cores(N, M, D, L, rng=rng, scale=M * 0.5 * 0.64 * D))
+    # max|f| of the un-calibrated 784-site chain underflows float64 products? no: ~1e-66, fine in float64
+    mo.calibrate(st, X.astype(np.float64))
+    cores32 = [c.astype(np.float32) for c in st.cores]
+    st = mo.MPSState(N, D, L, M, [c.astype(np.float64) for c in cores32])
+    return st, cores32
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reference-generated fixed-policy goldens at the bench's bond dimensions
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name,large', [('ltraj_fixed_M10', False), ('ltraj_fixed_M20', False), ('ltraj_fixed_M20', True),
+                                        ('ltraj_fixed_M50_L10', True)])
+def test_large_bond_goldens(name, large):
+    d = gu.load(name)
+    N, M, L, D = int(d['N']), int(d['M']), int(d['L']), int(d['D'])
+    kw = dict(lr=float(d['lr']), weight_dec=float(d['wd']), L2_flag=bool(d['L2_flag']), act_fn=str(d['act_fn']),
+              loss_fn=str(d['loss_fn']), T=float(d['T']), trunc=str(d['policy']))
+    X, y = d['X'], d['y']
+    ctx = hip().Context(N, D, L, M, X.shape[0])
+    ctx.set_cores(gu.indexed(d, 'init_core', N), 0)
+    ctx.set_input(X, y)
+    ctx.set_narrow_path(large)
+    ctx.debug_enable(True)
+    worst = dict(f=0.0, sigma=0.0, acc=0.0, mae=0.0, l2=0.0)
+    k = 0
+    for sw in range(int(d['n_sweeps'])):
+        assert relerr(ctx.forward(), d['sw%d_f_forward' % sw]) < 2e-3
+        left = bool(d['sw%d_left_dir' % sw])
+        for j in range(N - 1):
+            met, f_d = ctx.sweep(left, 1, j == 0, kw['lr'], kw['weight_dec'], kw['L2_flag'], kw['act_fn'], kw['loss_fn'],
+                                 kw['T'], kw['trunc'])
+            pre = 'st%d_' % k
+            S = d[pre + 'S']
+            sig = ctx.step_debug('sigma')
+            worst['sigma'] = max(worst['sigma'], np.abs(sig - S).max() / S.max())
+            worst['f'] = max(worst['f'], relerr(f_d, d[pre + 'f_new']))
+            worst['acc'] = max(worst['acc'], abs(float(met[0, 0]) - float(d[pre + 'accuracy'])))
+            worst['mae'] = max(worst['mae'], abs(float(met[0, 1]) - float(d[pre + 'MAE'])))
+            l2 = ctx.step_debug('scalars')[0]
+            worst['l2'] = max(worst['l2'], abs(l2 - float(d[pre + 'L2_loss'])) / abs(float(d[pre + 'L2_loss'])))
+            _, bond_d, _ = ctx.get_cores()
+            assert list(bond_d) == [int(v) for v in d[pre + 'bond']]
+            k += 1
+    print(name, 'large' if large else 'lds', {kk: '%.2e' % v for kk, v in worst.items()})
+    assert worst['f'] < 5e-3          # observed <= 2e-5
+    assert worst['sigma'] < 2e-3      # observed <= 1e-6
+    assert worst['acc'] < 1e-6
+    assert worst['mae'] < 2e-3
+    assert worst['l2'] < 1e-3
+    assert relerr(ctx.forward(), d['final_f']) < 5e-3
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C2 / C3 at their true shape
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cfg,N,M,b,L', [('c2', 784, 10, 1000, 2), ('c3', 784, 20, 5000, 2)])
+def test_bench_config_true_shape(cfg, N, M, b, L):
+    D = 2
+    X, y = synth(N, b, L, 1234)
+    X64 = X.astype(np.float64)
+    t0 = time.time()
+    st, cores32 = calibrated_pair(N, M, D, L, X, 99)
+    ctx = hip().Context(N, D, L, M, b)
+    ctx.set_cores(cores32, 0)
+    ctx.set_input(X, y)
+    obs = {}
+    for sw in range(2):
+        f_o = mo.forward(st, X64)
+        f_d = ctx.forward()
+        obs['fwd%d' % sw] = relerr(f_d, f_o)
+        left = st.l_pos == N - 1
+        vh = [[], []]
+        f_o = mo.sweep(st, X64, y, f_o, HP['lr'], HP['weight_dec'], L2_flag=True, left_dir=left, var_hist=vh,
+                       act_fn=HP['act_fn'], loss_fn=HP['loss_fn'], T=HP['T'], trunc='fixed')
+        met, f_d = ctx.sweep(left, N - 1, True, HP['lr'], HP['weight_dec'], True, HP['act_fn'], HP['loss_fn'], HP['T'], 'fixed')
+        obs['f%d' % sw] = relerr(f_d, f_o)
+        obs['acc%d' % sw] = float(np.abs(met[:, 0] - np.array(vh[0])).max())
+        obs['mae%d' % sw] = float(np.abs(met[:, 1] - np.array(vh[1])).max())
+        _, bond_d, lp = ctx.get_cores()
+        assert list(bond_d) == list(st.bond) and lp == st.l_pos
+        assert max(bond_d) == M and int(np.sum(np.asarray(bond_d) == M)) >= N - 1 - 2 * 6
+    X2, _ = synth(N, b, L, 4321)
+    ctx.set_input(X2, y)
+    obs['fresh'] = relerr(ctx.forward(), mo.forward(st, X2.astype(np.float64)))
+    ctx.close()
+    print(cfg, 'true shape', {k: '%.2e' % v for k, v in obs.items()}, '%.0f s' % (time.time() - t0))
+    for sw in range(2):
+        assert obs['fwd%d' % sw] < 5e-3
+        assert obs['f%d' % sw] < 1e-2             # 783 float32 steps against float64
+        assert obs['acc%d' % sw] <= 3.0 / b + 1e-6   # a borderline sample may flip its argmax in float32
+        assert obs['mae%d' % sw] < 2e-3
+    assert obs['fresh'] < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C5's true matrix shape (100 x 1000 merged tensor, n = 100 Jacobi, tiled wide kernel), step by step
+# ---------------------------------------------------------------------------------------------------------------
+def test_c5_true_matrix_shape():
+    N, M, b, L, D = 24, 50, 5000, 10, 2
+    X, y = synth(N, b, L, 77, zero_frac=0.6)
+    X64 = X.astype(np.float64)
+    st, cores32 = calibrated_pair(N, M, D, L, X, 5)
+    ctx = hip().Context(N, D, L, M, b)
+    ctx.set_cores(cores32, 0)
+    ctx.set_input(X, y)
+    y1h = mo.one_hot(y, L)
+    kw = dict(lr=1e-3, weight_dec=1e-3, L2_flag=True, act_fn='softmax', loss_fn='full_cross_ent', T=0.1, trunc='fixed')
+
+    def matricize(B, left):
+        ml, _, _, mr, _ = B.shape
+        return B.reshape(ml * D, D * mr * L) if not left else np.transpose(B, (0, 1, 4, 2, 3)).reshape(ml * D * L, D * mr)
+
+    worst = dict(f=0.0, sigma=0.0, prod=0.0, acc=0.0, mae=0.0)
+    shapes = set()
+    ctx.debug_enable(True)
+    for sw in range(2):
+        f_o = mo.forward(st, X64)
+        assert relerr(ctx.forward(), f_o) < 1e-3
+        left = st.l_pos == N - 1
+        if left:
+            st.Renv = {}
+        else:
+            st.Lenv = {}
+        for j in range(N - 1):
+            rec = {}
+            f_o = mo.sweep_step(st, f_o, y1h, left_dir=left, record=rec, **kw)
+            met, f_d = ctx.sweep(left, 1, j == 0, kw['lr'], kw['weight_dec'], True, kw['act_fn'], kw['loss_fn'], kw['T'], 'fixed')
+            shapes.add(rec['Bmat'].shape)
+            sig = ctx.step_debug('sigma')
+            worst['sigma'] = max(worst['sigma'], np.abs(sig - rec['S']).max() / rec['S'].max())
+            worst['f'] = max(worst['f'], relerr(f_d, f_o))
+            worst['acc'] = max(worst['acc'], abs(float(met[0, 0]) - rec['accuracy']))
+            worst['mae'] = max(worst['mae'], abs(float(met[0, 1]) - rec['MAE']))
+            # product of the two new cores against the best rank-m approximation of the DEVICE's updated tensor
+            Bm = matricize(ctx.step_debug('B_new').reshape(rec['B'].shape), left)
+            cores_d, bond_d, _ = ctx.get_cores()
+            p = rec['p']
+            m = int(bond_d[p])
+            A, C = cores_d[p].astype(np.float64), cores_d[p + 1].astype(np.float64)
+            prod = np.einsum('adkl,kec->adecl', A, C) if A.ndim == 4 else np.einsum('adk,kecl->adecl', A, C)
+            U, S, Vh = np.linalg.svd(Bm, full_matrices=False)
+            best = (U[:, :m] * S[:m]) @ Vh[:m]
+            worst['prod'] = max(worst['prod'], np.abs(matricize(prod, left) - best).max() / np.abs(Bm).max())
+            assert list(bond_d) == list(st.bond)
+    ctx.debug_enable(False)
+    print('c5 matrix shape', {k: '%.2e' % v for k, v in worst.items()}, sorted(shapes)[-3:])
+    assert (100, 1000) in shapes and (1000, 100) in shapes      # the C5 merged tensor, both directions
+    assert worst['f'] < 5e-3
+    assert worst['sigma'] < 2e-3
+    assert worst['prod'] < 5e-5
+    assert worst['acc'] <= 3.0 / b + 1e-6
+    assert worst['mae'] < 2e-3
+    X2, _ = synth(N, b, L, 78, zero_frac=0.6)
+    ctx.set_input(X2, y)
+    assert relerr(ctx.forward(), mo.forward(st, X2.astype(np.float64))) < 5e-3
+    ctx.close()
+
+
+def test_largest_matrix_side_of_the_large_path():
+    """min(rows, cols) = 128 is the limit of the Jacobi kernels (tnml_internal.h kBigMaxN): bond 64 at D = 2."""
+    N, M, b, L, D = 18, 64, 200, 3, 2
+    X, y = synth(N, b, L, 9, zero_frac=0.5)
+    X64 = X.astype(np.float64)
+    st, cores32 = calibrated_pair(N, M, D, L, X, 6)
+    ctx = hip().Context(N, D, L, M, b)
+    ctx.set_cores(cores32, 0)
+    ctx.set_input(X, y)
+    for sw in range(2):
+        f_o = mo.forward(st, X64)
+        assert relerr(ctx.forward(), f_o) < 1e-3
+        left = st.l_pos == N - 1
+        vh = [[], []]
+        f_o = mo.sweep(st, X64, y, f_o, 1e-2, 1e-3, L2_flag=True, left_dir=left, var_hist=vh, act_fn='softmax',
+                       loss_fn='full_cross_ent', T=0.1, trunc='fixed')
+        met, f_d = ctx.sweep(left, N - 1, True, 1e-2, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
+        assert relerr(f_d, f_o) < 5e-3
+        _, bond_d, lp = ctx.get_cores()
+        assert list(bond_d) == list(st.bond) and max(bond_d) == 64
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# accuracy parity of whole trainings (north star: "matching test accuracy within +-0.5 %")
+# ---------------------------------------------------------------------------------------------------------------
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def test_accuracy_parity_diagonals_training():
+    """training_diagonals.py's defaults (N = 64, M = 10, lr 0.01, L2_decay 1, softmax + full_cross_ent, reference
+    truncation, 5 epochs of one 4000-sample batch): Network.train on the device and the same loop on the oracle, from
+    the same cores and the same batches; validation accuracy per epoch within 0.5 %."""
+    import tensornetworkforml_amd  # noqa: F401
+    import data_generator as gen
+    import Network_class as tn
+    np.random.seed(11)
+    n_samples, ld, sigma, n_epochs, M = 5000, 8, 0.7, 5, 10
+    data, label = gen.create_dataset(n_samples, ld, sigma)
+    train_loader, val_loader, _ = gen.prepare_dataset(data, label, 1, 0.2, int(n_samples * 0.8), 128, 128)
+    # the batches of every epoch, drawn once and fed to both sides
+    epochs = [([(bt.X, bt.y) for bt in train_loader], [(bt.X, bt.y) for bt in val_loader]) for _ in range(n_epochs)]
+    x_cal = epochs[0][0][0][0]
+    with quiet():
+        net = tn.Network(N=ld * ld, M=M, L=2, calibration_X=x_cal, normalize=True, act_fn='softmax', loss_fn='full_cross_ent')
+    cores0 = [tn._tensor_to_core(A, i, net.N)[0] for i, A in enumerate(net.As)]
+    st = mo.MPSState(net.N, 2, 2, M, cores0, 0)
+
+    class Fixed:
+        def __init__(self, batches):
+            self.batches = batches
+
+        def __len__(self):
+            return len(self.batches)
+
+        def __iter__(self):
+            return iter([[(x_i, y_i) for x_i, y_i in zip(X, y)] for X, y in self.batches])
+
+    val_dev, val_orc = [], []
+    for tr, va in epochs:
+        with quiet():
+            v, _ = net.train(Fixed(tr), Fixed(va), lr=0.01, n_epochs=1, weight_dec=1.0)
+        val_dev.append(float(v[0]))
+        for X, y in tr:
+            f = mo.forward(st, X)
+            left = st.l_pos == st.N - 1
+            mo.sweep(st, X, y, f, 0.01, 1.0, L2_flag=True, left_dir=left, act_fn='softmax', loss_fn='full_cross_ent',
+                     T=0.1, trunc='reference')
+        val_orc.append(float(np.mean([mo.accuracy(mo.forward(st.copy(), X), y) for X, y in va])))
+    print('diagonals validation accuracy per epoch: device', val_dev, 'oracle', val_orc)
+    assert np.abs(np.array(val_dev) - np.array(val_orc)).max() <= 0.005
+    assert val_dev[-1] >= 0.97 and val_orc[-1] >= 0.97          # the task is learnt (reference: 1.0, results/diag_accuracy.png)
+
+
+def test_accuracy_parity_mnist_shaped():
+    """N = 196 (the 14 x 14 pooled MNIST shape training_binary_MNIST.py really runs), bond 20 fixed, batch 1000, four
+    sweeps over four different synthetic batches with a learnable label (brightness of the upper half vs the lower):
+    training accuracy of every step and accuracy on a held-out batch, device vs oracle, within 0.5 %."""
+    N, M, b, L, D = 196, 20, 1000, 2, 2
+
+    def batch(seed):
+        rng = np.random.default_rng(seed)
+        p = rng.random((b, N), dtype=np.float32) * (rng.random((b, N), dtype=np.float32) > 0.81)
+        y = (p[:, :N // 2].sum(1) > p[:, N // 2:].sum(1)).astype(np.int32)
+        X = np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32)
+        return X, y
+
+    batches = [batch(100 + i) for i in range(4)]
+    Xh, yh = batch(999)
+    st, cores32 = calibrated_pair(N, M, D, L, batches[0][0], 3)
+    ctx = hip().Context(N, D, L, M, b)
+    ctx.set_cores(cores32, 0)
+    worst_acc = 0.0
+    for X, y in batches:
+        ctx.set_input(X, y)
+        f_o = mo.forward(st, X.astype(np.float64))
+        ctx.forward(want_f=False)
+        left = st.l_pos == N - 1
+        vh = [[], []]
+        mo.sweep(st, X.astype(np.float64), y, f_o, 1e-2, 1e-3, L2_flag=True, left_dir=left, var_hist=vh, act_fn='softmax',
+                 loss_fn='full_cross_ent', T=0.1, trunc='fixed')
+        met, _ = ctx.sweep(left, N - 1, True, 1e-2, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
+        worst_acc = max(worst_acc, float(np.abs(met[:, 0] - np.array(vh[0])).max()))
+    ctx.set_input(Xh, yh)
+    acc_d = mo.accuracy(ctx.forward(), yh)
+    acc_o = mo.accuracy(mo.forward(st.copy(), Xh.astype(np.float64)), yh)
+    ctx.close()
+    print('MNIST-shaped: worst per-step training accuracy gap %.4f; held-out accuracy device %.4f oracle %.4f' % (worst_acc, acc_d, acc_o))
+    assert worst_acc <= 0.005
+    assert abs(acc_d - acc_o) <= 0.005
