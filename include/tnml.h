@@ -155,6 +155,12 @@ int tnml_predict(tnml_ctx *ctx, const float *X, int b, float *f_out);
  * 1e-8 costs one more and reaches ~1e-6.  Allowed range [1e-12, 1e-2]. */
 int tnml_set_svd_stop(tnml_ctx *ctx, double stop2);
 
+/* A sweep step is ONE launch by default: workgroup 0 updates and splits the merged tensor of step k while the other
+ * workgroups of the same launch form f of step k and the batch-summed pre-gradient of step k+1.
+ * on = 0 restores the classic sequence (batch kernel -> [reduction] -> update/SVD kernel), which is also what steps
+ * whose merged tensor does not fit one workgroup's LDS take.  Results agree to float32 rounding. */
+int tnml_set_step_pipeline(tnml_ctx *ctx, int on);
+
 /* tnml_sweep enqueues every launch of its n_steps steps without waiting (2 - 14 launches per step).  A profiler that
  * intercepts dispatches (rocprofv3 --pmc serialises them and keeps per-dispatch state) can be overrun by tens of
  * thousands of queued launches; n_steps > 0 drains the stream every n_steps steps, 0 (default) never. */

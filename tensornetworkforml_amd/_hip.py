@@ -27,7 +27,7 @@ SYMBOLS = [
     'tnml_get_step_debug', 'tnml_l_pos', 'tnml_batch', 'tnml_timer_start', 'tnml_timer_stop',
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
     'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict', 'tnml_set_trunc_threshold',
-    'tnml_set_sync_interval',
+    'tnml_set_sync_interval', 'tnml_set_step_pipeline',
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
         L.tnml_predict.argtypes = [vp, f32p, C.c_int, f32p]
         L.tnml_set_trunc_threshold.argtypes = [vp, C.c_double]
         L.tnml_set_sync_interval.argtypes = [vp, C.c_int]
+        L.tnml_set_step_pipeline.argtypes = [vp, C.c_int]
         L.tnml_svd_split.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f64p]
         _lib = L
     return _lib
@@ -311,6 +312,10 @@ class Context:
     def set_trunc_threshold(self, threshold):
         """Cumulative-share threshold of trunc='adaptive' (default 0.999)."""
         _chk(lib().tnml_set_trunc_threshold(self._h, float(threshold)))
+
+    def set_step_pipeline(self, on):
+        """True (default): one launch per sweep step (pipelined); False: the classic launch sequence."""
+        _chk(lib().tnml_set_step_pipeline(self._h, int(bool(on))))
 
     def set_sync_interval(self, n_steps):
         """Drain the stream every n_steps sweep steps (0: never); for runs under a dispatch-intercepting profiler."""

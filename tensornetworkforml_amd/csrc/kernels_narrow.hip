@@ -25,6 +25,7 @@
 #include "tnml_internal.h"
 #include "jacobi_device.h"
 #include "small_gemm_device.h"
+#include "wide_pipe_device.h"
 
 namespace tnml {
 
@@ -152,16 +153,16 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
   }
 }
 
-__global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (p.fused && blockIdx.x > 0) { narrow_helper_block(p, smem_raw); return; }
+__device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char *smem_raw) {
   const NarrowCarve k = narrow_carve(smem_raw, p.h, p.g, p.s, p.L, p.m);
   const int tid = threadIdx.x, NT = kNarrowThreads;
   const int D = kD, h = p.h, g = p.g, s = p.s, L = p.L, m = p.m, Bs = p.bsize;
   // reduced gradient + metric tail: written by other workgroups of THIS launch when fused -> coherent loads
   auto ldred = [&](int e) -> float {
-    return p.fused ? __hip_atomic_load(p.red + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.red[e];
+    return (p.fused && !p.pipe) ? __hip_atomic_load(p.red + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.red[e];
   };
+  // metric sums of the batch-side workgroups: behind the gradient (classic) or behind the reduced pre-gradient (pipelined)
+  auto ldtail = [&](int i) -> float { return p.pipe ? p.zred[p.zsize + i] : ldred(p.bsize + i); };
   const int r = D * h, c = D * g * L;
   const bool short_rows = (r <= c);
   const int n = short_rows ? r : c, ne = n + (n & 1), len = short_rows ? c : r;
@@ -176,6 +177,17 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 #endif
 #define TNML_STAMP(i) if (p.stamps && tid == 0) t_p[i] = __builtin_amdgcn_s_memtime()
   if (p.stamps && tid == 0) { t_c0 = __builtin_amdgcn_s_memtime(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
+  // ---- pipelined step: raw gradient dB[h_, rest] = sum_i' A_{k-1}[i', h_] Z_k[i', rest] (wide_pipe_device.h); both operands
+  // were completed by the previous launch, so this runs before anything of this launch is waited for
+  const int RWz = kD * kD * p.g * p.L;
+  if (p.pipe && !p.z_first) {
+    const float *zc = p.zcore.base;
+    const int zs_in = p.zcore.s_in, zs_d = p.zcore.s_d, zs_out = p.zcore.s_out;
+    small_gemm_f64(1, h, RWz, p.z_rows,
+                   [&](int, int i, int kk) { return (double)zc[(kk >> 1) * zs_in + (kk & 1) * zs_d + i * zs_out]; },
+                   [&](int, int kk, int j) { return (double)p.zred[(size_t)kk * RWz + j]; },
+                   [&](int, int i, int j, double v) { k.dT[i * RWz + j] = v; });
+  }
   // ---- phase 0: stage the two cores and the norm environments ---------------------------------
   if (p.fused) {
     // B and Ln.B.Rn come from the slice workgroups of the preceding wide launch (prep_ready: plain loads, issued
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
         if (p.l2_flag) k.dG[e] = p.prepG[e];
       }
     if (tid == 0) {
-      const unsigned want = gridDim.x - 1;
+      const unsigned want = (unsigned)p.wait_count;
       int spins = 0;
       while (__hip_atomic_load(p.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1 << 22)) {
         __builtin_amdgcn_s_sleep(8);
@@ -270,14 +282,14 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 #pragma unroll
   for (int u = 0; u < kMaxPer; ++u) {                     // all loads of the reduced gradient in flight together
     const int e = tid + u * NT;
-    redv[u] = e < Bs ? ldred(e) : 0.f;
+    redv[u] = (e < Bs && !(p.pipe && !p.z_first)) ? ldred(e) : 0.f;
   }
 #pragma unroll
   for (int u = 0; u < kMaxPer; ++u) {
     const int e = tid + u * NT;
     if (e >= Bs) break;
     const double bv = (double)k.fB[e];
-    const double raw = (double)redv[u];
+    const double raw = (p.pipe && !p.z_first) ? k.dT[e] : (double)redv[u];
     double wdterm;
     if (p.l2_flag) {
       const double gv = k.dG[e];
@@ -310,9 +322,10 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
       const float v = (float)((double)k.fB[e] + factor * k.dG[e]);
       k.fB[e] = v;
       k.fBp[row * (c + 1) + x] = v;
-      p.Bnew[e] = v;
+      if (p.flag) st_sc1(p.Bnew + e, v); else p.Bnew[e] = v;
       if (p.dbg) p.dbg[2 * (size_t)Bs + e] = (double)v;
     }
+  if (p.flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its stores before the barrier
   if (tid == 0) {
     if (bad) atomicOr(p.status, 1);
     if (p.dbg) {
@@ -324,12 +337,15 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
   }
   XSTAMP(2);
   __syncthreads();   // dT/dG are dead from here on; Z aliases them
+  // B_new is complete in memory: the batch-side workgroups of this launch may form f and the next pre-gradient from it
+  // while this workgroup goes on to the SVD
+  if (p.flag && tid == 0) __hip_atomic_store(p.flag, p.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (p.stop_after_update) {                       // standalone update_B / compute_L2_reg
     if (tid == 0 && p.metrics) {
-      const double cnt = (double)ldred(Bs + 3);
+      const double cnt = (double)ldtail(3);
       const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
-      p.metrics[0] = (float)((double)ldred(Bs) * inv);
-      p.metrics[1] = (float)((double)ldred(Bs + 1) * inv / (double)L);
+      p.metrics[0] = (float)((double)ldtail(0) * inv);
+      p.metrics[1] = (float)((double)ldtail(1) * inv / (double)L);
     }
     return;
   }
@@ -881,11 +897,11 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 
   // ---- phase 11: metrics of this step (var_hist, Network_class.py:739-750) --------------------------
   if (tid == 0 && p.metrics) {
-    const double cnt = (double)ldred(Bs + 3);
+    const double cnt = (double)ldtail(3);
     const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
-    p.metrics[0] = (float)((double)ldred(Bs) * inv);
-    p.metrics[1] = (float)((double)ldred(Bs + 1) * inv / (double)L);
-    if (ldred(Bs + 2) != 0.f) atomicOr(p.status, 1);
+    p.metrics[0] = (float)((double)ldtail(0) * inv);
+    p.metrics[1] = (float)((double)ldtail(1) * inv / (double)L);
+    if (ldtail(2) != 0.f) atomicOr(p.status, 1);
   }
 #ifdef TNML_EXP_ROUND_TIMING
   // timing experiment (tools/build_exp.sh): ne-1 rounds each with parts of the round switched off, on the
@@ -907,8 +923,32 @@ __global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParam
 #endif
 }
 
+// classic step: one narrow launch (workgroup 0 + optional reduce / slice helpers)
+__global__ __launch_bounds__(kNarrowThreads) void narrow_step_kernel(NarrowParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (p.fused && blockIdx.x > 0) { narrow_helper_block(p, smem_raw); return; }
+  narrow_body(p, smem_raw);
+}
+
 void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st) {
-  hipLaunchKernelGGL(narrow_step_kernel, dim3(p.fused ? 1 + p.nred + (p.prep_ready ? 0 : kD * kD) : 1), dim3(kNarrowThreads), lds_bytes, st, p);
+  hipLaunchKernelGGL(narrow_step_kernel, dim3(p.fused ? 1 + p.wait_count : 1), dim3(kNarrowThreads), lds_bytes, st, p);
+}
+
+// pipelined step (wide_pipe_device.h): ONE launch per sweep step.  Block 0 updates and splits the merged tensor of step k,
+// blocks 1..4 are its slice helpers (merged tensor and L2 term of step k), blocks w.wg0.. are the batch-side workgroups
+// that turn B_new(k) into f and the pre-gradient of step k+1 while block 0 runs the SVD.  With w.wg0 == 0 the launch
+// carries batch-side workgroups only (start of a sweep, or after a classic step).
+__global__ __launch_bounds__(kNarrowThreads) void step_pipe_kernel(NarrowParams p, WidePipeParams w) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int blk = blockIdx.x;
+  if (blk >= w.wg0) { wide_pipe_block(w, (float *)smem_raw); return; }
+  if (blk > 0) { narrow_helper_block(p, smem_raw); return; }
+  narrow_body(p, smem_raw);
+}
+
+void launch_step_pipe(const NarrowParams &p, const WidePipeParams &w, size_t lds_bytes, hipStream_t st) {
+  const int grid = w.wg0 + (w.do_f || w.do_z || w.do_ext ? w.nwide : 0);
+  hipLaunchKernelGGL(step_pipe_kernel, dim3(grid), dim3(kNarrowThreads), lds_bytes, st, p, w);
 }
 
 // ------------------------------------------------------------------------------------------

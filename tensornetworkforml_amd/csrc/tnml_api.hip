@@ -11,6 +11,8 @@
 #include <cstdlib>
 
 #include "tnml_internal.h"
+#include "small_gemm_device.h"
+#include "wide_pipe_device.h"
 
 using namespace tnml;
 
@@ -84,6 +86,15 @@ struct tnml_ctx {
   float *prepB = nullptr;                    // fused narrow launch: merged tensor / L2 term from the helper workgroups
   double *prepG = nullptr;
   unsigned *sync = nullptr;
+  // pipelined step (wide_pipe_device.h): partial / group / reduced pre-gradients, arrival counters, B_new flag
+  bool pipe_enabled = true;                  // tnml_set_step_pipeline
+  float *zslabs = nullptr, *gslabs = nullptr, *zred = nullptr;
+  unsigned *pipe_cnt = nullptr;              // [0..15] group counters, [16] top counter, [17] flag
+  int zstride = 0, pipe_nwide = 0, pipe_tpw = 1, pipe_ngroups = 0;
+  bool Z_valid = false;                      // zred holds the pre-gradient of relative step Z_k of a sweep in direction Z_left
+  int Z_k = -1, Z_left = 0, Z_act = 0, Z_loss = 0;
+  float Z_T = 0.f;
+  unsigned token = 0;
   float *Xpred_stage = nullptr, *Xpred = nullptr, *fpred = nullptr;   // tnml_predict's own batch (the resident one is untouched)
   int pred_cap = 0;
   int slab_stride = 0, nblk_cap = 0, metrics_cap = 0;
@@ -136,7 +147,7 @@ static int alloc_batch_buffers(tnml_ctx *c, int b_cap) {
   const int b_pad = (b_cap + 63) / 64 * 64;
   auto freep = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
   freep(c->X); freep(c->Xstage); freep(c->y); freep(c->f); freep(c->ftmp); freep(c->ftmp2);
-  freep(c->Lenv); freep(c->Renv); freep(c->slabs);
+  freep(c->Lenv); freep(c->Renv); freep(c->slabs); freep(c->zslabs);
   c->b_cap = b_cap;
   c->b_pad = b_pad;
   const size_t env_elems = (size_t)c->N * c->Mmax * b_pad;
@@ -150,6 +161,15 @@ static int alloc_batch_buffers(tnml_ctx *c, int b_cap) {
   HIP_TRY(hipMalloc(&c->Renv, env_elems * sizeof(float)));
   c->nblk_cap = b_pad / kTS;
   HIP_TRY(hipMalloc(&c->slabs, (size_t)c->nblk_cap * c->slab_stride * sizeof(float)));
+  {   // batch-side workgroups of the pipelined step: at most kPipeMaxWide, each looping over pipe_tpw sample tiles
+    constexpr int kPipeMaxWide = 240;
+    const int ntiles = b_pad / kTS;
+    c->pipe_tpw = (ntiles + kPipeMaxWide - 1) / kPipeMaxWide;
+    c->pipe_nwide = (ntiles + c->pipe_tpw - 1) / c->pipe_tpw;
+    c->pipe_ngroups = (c->pipe_nwide + kPipeGroupMax - 1) / kPipeGroupMax;
+    HIP_TRY(hipMalloc(&c->zslabs, (size_t)c->pipe_nwide * c->zstride * sizeof(float)));
+  }
+  c->Z_valid = false;
   HIP_TRY(hipMemsetAsync(c->y, 0, (size_t)b_pad * sizeof(int), c->stream));
   HIP_TRY(hipMemsetAsync(c->f, 0, (size_t)c->L * b_pad * sizeof(float), c->stream));
   c->have_input = c->have_labels = false;
@@ -198,6 +218,11 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipMalloc(&c->prepG, c->bmax * sizeof(double)));
   HIP_TRY(hipMalloc(&c->sync, sizeof(unsigned)));
   HIP_TRY(hipMemset(c->sync, 0, sizeof(unsigned)));
+  c->zstride = (int)((2 * c->bmax + kMetricSlots + 63) / 64 * 64);       // Z has up to D times the elements of the gradient
+  HIP_TRY(hipMalloc(&c->gslabs, (size_t)kPipeGroupMax * c->zstride * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->zred, (size_t)c->zstride * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->pipe_cnt, 32 * sizeof(unsigned)));
+  HIP_TRY(hipMemset(c->pipe_cnt, 0, 32 * sizeof(unsigned)));
   HIP_TRY(hipMalloc(&c->Bscr2, c->bmax * sizeof(float)));
   HIP_TRY(hipMalloc(&c->red, (size_t)c->slab_stride * sizeof(float)));
   c->metrics_cap = N;
@@ -225,7 +250,7 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->comm) ncclCommDestroy(c->comm);
   void *ptrs[] = {c->X, c->Xstage, c->y, c->f, c->ftmp, c->ftmp2, c->Lenv, c->Renv, c->cores, c->lab[0], c->lab[1],
                   c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2,
-                  c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
+                  c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->zslabs, c->gslabs, c->zred, c->pipe_cnt, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -236,11 +261,27 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   return TNML_OK;
 }
 
+// the device status word is sticky: read and clear it (the stream must be idle)
+static int check_status(tnml_ctx *c) {
+  int st = 0;
+  HIP_TRY(hipMemcpy(&st, c->status, sizeof(int), hipMemcpyDeviceToHost));
+  if (!st) return TNML_OK;
+  HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
+  if (st & 12) {
+    HIP_TRY(hipMemset(c->sync, 0, sizeof(unsigned)));          // a late helper may have left the arrival counter mid-count
+    HIP_TRY(hipMemset(c->pipe_cnt, 0, 17 * sizeof(unsigned)));
+    c->Z_valid = false;
+    return fail(TNML_ERR_STATE, "internal: a workgroup of a sweep-step launch never saw its hand-off (status %d)", st);
+  }
+  if (st & 1) return fail(TNML_ERR_NONFINITE, "non-finite values reached the bond update / SVD (status %d)", st);
+  return fail(TNML_ERR_NONFINITE, "Jacobi SVD did not converge (status %d)", st);
+}
+
 extern "C" int tnml_synchronize(tnml_ctx *c) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return TNML_OK;
+  return check_status(c);       // failures inside sweeps that handed nothing back surface here
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -313,6 +354,7 @@ extern "C" int tnml_set_cores(tnml_ctx *c, const float *flat, size_t n_floats, c
   c->Ln_valid = c->Rn_valid = false;
   c->f_current = false;
   c->Bnew_valid = false;
+  c->Z_valid = false;
   return TNML_OK;
 }
 
@@ -358,6 +400,7 @@ extern "C" int tnml_scale_cores(tnml_ctx *c, double factor) {
   c->Ln_valid = c->Rn_valid = false;
   c->f_current = false;
   c->Bnew_valid = false;
+  c->Z_valid = false;
   return TNML_OK;
 }
 
@@ -392,6 +435,7 @@ extern "C" int tnml_set_input(tnml_ctx *c, const float *X, const int32_t *y, int
   c->envs_valid_L = c->envs_valid_R = false;
   c->f_current = false;
   c->Bnew_valid = false;
+  c->Z_valid = false;
   return TNML_OK;
 }
 
@@ -406,6 +450,7 @@ extern "C" int tnml_set_labels(tnml_ctx *c, const int32_t *y, int b) {
   HIP_TRY(hipMemcpyAsync(c->y, y, (size_t)b * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_labels = true;
+  c->Z_valid = false;             // the pre-gradient carries the loss derivative of the old labels
   return TNML_OK;
 }
 
@@ -476,6 +521,7 @@ static int run_chain(tnml_ctx *c, bool logmode) {
     c->envs_valid_L = !right_envs;
     c->f_current = true;
     c->Bnew_valid = false;
+    c->Z_valid = false;
   }
   return TNML_OK;
 }
@@ -566,6 +612,7 @@ extern "C" int tnml_set_f(tnml_ctx *c, const float *f) {
                            (size_t)c->b * sizeof(float), c->L, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->f_current = true;
+  c->Z_valid = false;             // a pre-gradient computed from the device's own f no longer applies
   return TNML_OK;
 }
 
@@ -675,6 +722,57 @@ static void prof_end(tnml_ctx *c, int which) {
   (void)hipEventElapsedTime(&ms, c->pev0, c->pev1);
   c->prof_ms[which] += ms;
   c->prof_n[which]++;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pipelined step (wide_pipe_device.h): operands of the batch-side workgroups for base step j (relative index; -1 = start of
+// a sweep), i.e. f from B_new(j) and the pre-gradient Z of step j+1.  Relative site t is absolute site t (right sweep)
+// or N-1-t (left sweep); E_t (behind environment of step t) lives in the behind stack's slot of relative site t-1, the
+// ahead environment of step t in the ahead stack's slot of relative site t+2.
+// ---------------------------------------------------------------------------------------------
+static void fill_wide_pipe(tnml_ctx *c, WidePipeParams &w, int left_dir, int j, int act_fn, int loss_fn, float T) {
+  const int N = c->N, D = c->D;
+  auto ab = [&](int t) { return left_dir ? N - 1 - t : t; };                       // relative -> absolute site
+  auto rb = [&](int t) { return left_dir ? c->bond[N - 2 - t] : c->bond[t]; };     // bond between relative sites t, t+1
+  float *beh = left_dir ? c->Renv : c->Lenv;
+  float *ahe = left_dir ? c->Lenv : c->Renv;
+  auto xs = [&](int t) -> const float * { return (t >= 0 && t <= N - 1) ? c->X + (size_t)ab(t) * c->b_pad * D : nullptr; };
+  w = WidePipeParams{};
+  w.b = c->b; w.b_pad = c->b_pad; w.L = c->L;
+  w.first = j < 0;
+  w.hj = j >= 1 ? rb(j - 1) : 1;
+  w.gj = (j >= 0 && j + 1 <= N - 2) ? rb(j + 1) : 1;
+  w.gn = (j + 2 <= N - 2) ? rb(j + 2) : 1;
+  w.hprev = j >= 2 ? rb(j - 2) : 1;
+  w.first_ext = (j == 1);
+  w.act_fn = act_fn; w.loss_fn = loss_fn; w.T = T;
+  w.x_jm1 = xs(j - 1); w.x_j = xs(j); w.x_jp1 = xs(j + 1); w.x_jp2 = xs(j + 2);
+  w.Eprev = j >= 2 ? c->env_slot(beh, ab(j - 2)) : nullptr;
+  w.Ecur = j >= 1 ? c->env_slot(beh, ab(j - 1)) : nullptr;
+  if (j >= 1) {
+    w.ext_core.base = c->core_slot(ab(j - 1));
+    w.ext_core.n_in = w.hprev; w.ext_core.n_out = w.hj;
+    if (!left_dir) { w.ext_core.s_in = D * w.hj; w.ext_core.s_d = w.hj; w.ext_core.s_out = 1; }
+    else { w.ext_core.s_in = 1; w.ext_core.s_d = w.hprev; w.ext_core.s_out = D * w.hprev; }
+  }
+  w.Gj = (j >= 0 && j + 2 <= N - 1) ? c->env_slot(ahe, ab(j + 2)) : nullptr;
+  w.Gn = (j + 3 <= N - 1) ? c->env_slot(ahe, ab(j + 3)) : nullptr;
+  w.Bnew = c->Bnew;
+  w.y = c->y; w.f = c->f;
+  w.zsize = (w.first ? 1 : w.hj * D) * D * D * w.gn * c->L;
+  w.slab_stride = c->zstride;
+  w.slabs = c->zslabs; w.gslabs = c->gslabs; w.zred = c->zred;
+  w.gcnt = c->pipe_cnt; w.tcnt = c->pipe_cnt + 16;
+  w.nwide = c->pipe_nwide; w.gsz = kPipeGroupMax; w.ngroups = c->pipe_ngroups;
+  w.tiles_per_wg = c->pipe_tpw; w.ntiles = c->b_pad / kTS;
+  w.flag = c->pipe_cnt + 17;
+  w.status = c->status;
+}
+
+static bool wide_pipe_fits(const tnml_ctx *c, const WidePipeParams &w) {
+  if (wide_pipe_lds_bytes(w) > 160 * 1024) return false;
+  if (w.do_z && (wide_pipe_ztiles(w) > 16 * kPipeMaxZT || w.zsize + kMetricSlots > c->zstride)) return false;
+  return true;
 }
 
 // f-part operands for "the step that just ended" seen from relative step index k (k >= 1):
@@ -809,73 +907,122 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + kDbgSigma + 5 : nullptr;
     n.status = c->status;
     n.counters = c->counters;
-    // ---- wide kernel -----------------------------------------------------------------------
-    WideParams w{};
-    w.b = c->b; w.b_pad = c->b_pad; w.L = L;
-    w.h = h; w.g = g;
-    w.act_fn = act_fn; w.loss_fn = loss_fn; w.T = T;
-    w.y = c->y; w.f = c->f;
-    w.slabs = c->slabs; w.slab_stride = c->slab_stride; w.bsize = (int)bsize;
-    w.x_k = c->X + (size_t)sb * c->b_pad * D;
-    w.x_kp1 = c->X + (size_t)sa * c->b_pad * D;
-    w.hp = 1; w.gp = 1;
-    w.do_ext = (k >= 1);
-    w.first_ext = (k == 1);
-    if (k >= 1) {
-      const int e_site = left_dir ? p + 2 : p - 1;          // site t = k-1, plain since the previous step
-      const int hp = left_dir ? c->mr(e_site) : c->ml(e_site);
-      w.hp = hp;
-      w.x_km1 = c->X + (size_t)e_site * c->b_pad * D;
-      w.ext_core.base = c->core_slot(e_site);
-      w.ext_core.n_in = hp; w.ext_core.n_out = h;
-      if (!left_dir) { w.ext_core.s_in = D * h; w.ext_core.s_d = h; w.ext_core.s_out = 1; }
-      else { w.ext_core.s_in = 1; w.ext_core.s_d = hp; w.ext_core.s_out = D * hp; }
-      w.Hprev = (k >= 2) ? c->env_slot(beh, left_dir ? p + 3 : p - 2) : nullptr;
-      w.Hcur = c->env_slot(beh, left_dir ? p + 2 : p - 1);
-    }
-    if (c->Bnew_valid && !c->f_current) {
-      // f of the previous step from its updated B: that step acted on sites t = k-1, k
-      if (k < 1 || c->prev_h != w.hp || c->prev_g != s)
-        return fail(TNML_ERR_STATE, "internal: previous-step dims (%d,%d) do not match (%d,%d)", c->prev_h, c->prev_g, w.hp, s);
-      w.do_f = 1;
-      w.gp = s;
-      w.Gprev = c->env_slot(ahe, left_dir ? p : p + 1);     // sites t > k
-      w.Bprev = c->Bnew;
-    }
-    {
-      const int gs = left_dir ? p - 1 : p + 2;
-      w.Gcur = (gs >= 0 && gs <= N - 1) ? c->env_slot(ahe, gs) : nullptr;
-    }
-    w.stamps = c->stamps ? c->dbg + 4 * c->bmax + kDbgSigma + 5 + 17 : nullptr;
-    PrepParams prep{};
-    prep.lab = n.lab; prep.pl = n.pl; prep.Nh = n.Nh; prep.Ng = n.Ng; prep.h = h; prep.g = g; prep.s = s; prep.L = L;
-    prep.l2_flag = n.l2_flag; prep.prepB = c->prepB; prep.prepG = c->prepG;
-    prof_begin(c);
-    n.prep_ready = launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream) ? 1 : 0;
-    prof_end(c, 1);
-    // ---- reduce (+ all-reduce over the batch shards) -----------------------------------------
-    if (!fused) {
-      prof_begin(c);
-      launch_reduce(c->slabs, nblk, c->slab_stride, (int)bsize + kMetricSlots, c->red, c->stream);
-      prof_end(c, 2);
-    }
-    if (c->comm) NCCL_TRY(ncclAllReduce(c->red, c->red, bsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
-    prof_begin(c);
-    { int rc = run_narrow(c, n, npath); if (rc) return rc; }
-    prof_end(c, 3);
-    {   // diagnostic: TNML_EXTRA_LAUNCHES=k adds k trivial dependent launches per step (prices a boundary)
-      static const int extra = getenv("TNML_EXTRA_LAUNCHES") ? atoi(getenv("TNML_EXTRA_LAUNCHES")) : 0;
-      for (int x = 0; x < extra; ++x) launch_scale(c->scal, 1, 1.0f, c->stream);
-    }
-    c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
-    if (mode == 1) {
-      // the behind environment list grew (as update_B does, Network_class.py:637-652); nothing else changes
-      HIP_TRY(hipGetLastError());
-      if (metrics_out) {
-        HIP_TRY(hipMemcpyAsync(metrics_out, c->metrics, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+    // ---- pipelined step: ONE launch (update + SVD of step k next to the batch-side work of step k+1) ----------------
+    bool pipe = c->pipe_enabled && fuse_ok && npath == 0 && mode == 0 && !Bdirect_dev;
+    WidePipeParams wp{}, wpro{};
+    bool need_prologue = false;
+    if (pipe) {
+      fill_wide_pipe(c, wp, left_dir, k, act_fn, loss_fn, T);
+      wp.do_ext = k >= 1; wp.do_f = 1; wp.wait_flag = 1;
+      wp.do_z = (k + 1 <= N - 2);
+      if (wp.do_z && !wide_pipe_fits(c, wp)) wp.do_z = 0;            // the next step will start from its own prologue
+      if (!wide_pipe_fits(c, wp)) pipe = false;
+      const bool zok = c->Z_valid && c->Z_k == k && c->Z_left == left_dir && c->Z_act == act_fn && c->Z_loss == loss_fn && c->Z_T == T;
+      if (pipe && !zok) {
+        fill_wide_pipe(c, wpro, left_dir, k - 1, act_fn, loss_fn, T);
+        wpro.do_ext = 0; wpro.wait_flag = 0; wpro.do_z = 1;
+        wpro.do_f = (k >= 1 && c->Bnew_valid && !c->f_current) ? 1 : 0;
+        if (wpro.do_f && (c->prev_h != wpro.hj || c->prev_g != wpro.gj))
+          return fail(TNML_ERR_STATE, "internal: previous-step dims (%d,%d) do not match (%d,%d)", c->prev_h, c->prev_g, wpro.hj, wpro.gj);
+        if (!wide_pipe_fits(c, wpro)) pipe = false; else need_prologue = true;
       }
-      return TNML_OK;
+    }
+    if (pipe) {
+      if (need_prologue) {
+        NarrowParams none{};
+        wpro.wg0 = 0;
+        prof_begin(c);
+        launch_step_pipe(none, wpro, wide_pipe_lds_bytes(wpro), c->stream);
+        prof_end(c, 1);
+        if (c->comm) NCCL_TRY(ncclAllReduce(c->zred, c->zred, wpro.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
+        if (wpro.do_f) c->f_current = true;
+      }
+      n.fused = 1; n.nred = 0; n.prep_ready = 0; n.wait_count = kD * kD; n.sync = c->sync; n.red_out = nullptr;
+      n.pipe = 1; n.z_first = (k == 0); n.z_rows = wp.hprev * D;
+      n.zsize = (k == 0 ? 1 : n.z_rows) * D * D * g * L;
+      n.zred = c->zred; n.red = c->zred; n.zcore = wp.ext_core;
+      n.flag = c->pipe_cnt + 17; n.token = ++c->token;
+      wp.token = n.token;
+      wp.wg0 = 1 + kD * kD;
+      size_t lds = std::max(narrow_lds_bytes(h, g, s, L, m), wide_pipe_lds_bytes(wp));
+      lds = std::max(lds, prep_slice_lds_bytes(h, g, s, L));
+      if (lds > 160 * 1024) return fail(TNML_ERR_ARG, "internal: pipelined step needs %zu bytes of LDS", lds);
+      prof_begin(c);
+      launch_step_pipe(n, wp, lds, c->stream);
+      prof_end(c, 3);
+      if (c->comm && wp.do_z) NCCL_TRY(ncclAllReduce(c->zred, c->zred, wp.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
+      c->Z_valid = wp.do_z != 0; c->Z_k = k + 1; c->Z_left = left_dir; c->Z_act = act_fn; c->Z_loss = loss_fn; c->Z_T = T;
+    } else {
+      c->Z_valid = false;
+      // ---- wide kernel -----------------------------------------------------------------------
+      WideParams w{};
+      w.b = c->b; w.b_pad = c->b_pad; w.L = L;
+      w.h = h; w.g = g;
+      w.act_fn = act_fn; w.loss_fn = loss_fn; w.T = T;
+      w.y = c->y; w.f = c->f;
+      w.slabs = c->slabs; w.slab_stride = c->slab_stride; w.bsize = (int)bsize;
+      w.x_k = c->X + (size_t)sb * c->b_pad * D;
+      w.x_kp1 = c->X + (size_t)sa * c->b_pad * D;
+      w.hp = 1; w.gp = 1;
+      w.do_ext = (k >= 1);
+      w.first_ext = (k == 1);
+      if (k >= 1) {
+        const int e_site = left_dir ? p + 2 : p - 1;          // site t = k-1, plain since the previous step
+        const int hp = left_dir ? c->mr(e_site) : c->ml(e_site);
+        w.hp = hp;
+        w.x_km1 = c->X + (size_t)e_site * c->b_pad * D;
+        w.ext_core.base = c->core_slot(e_site);
+        w.ext_core.n_in = hp; w.ext_core.n_out = h;
+        if (!left_dir) { w.ext_core.s_in = D * h; w.ext_core.s_d = h; w.ext_core.s_out = 1; }
+        else { w.ext_core.s_in = 1; w.ext_core.s_d = hp; w.ext_core.s_out = D * hp; }
+        w.Hprev = (k >= 2) ? c->env_slot(beh, left_dir ? p + 3 : p - 2) : nullptr;
+        w.Hcur = c->env_slot(beh, left_dir ? p + 2 : p - 1);
+      }
+      if (c->Bnew_valid && !c->f_current) {
+        // f of the previous step from its updated B: that step acted on sites t = k-1, k
+        if (k < 1 || c->prev_h != w.hp || c->prev_g != s)
+          return fail(TNML_ERR_STATE, "internal: previous-step dims (%d,%d) do not match (%d,%d)", c->prev_h, c->prev_g, w.hp, s);
+        w.do_f = 1;
+        w.gp = s;
+        w.Gprev = c->env_slot(ahe, left_dir ? p : p + 1);     // sites t > k
+        w.Bprev = c->Bnew;
+      }
+      {
+        const int gs = left_dir ? p - 1 : p + 2;
+        w.Gcur = (gs >= 0 && gs <= N - 1) ? c->env_slot(ahe, gs) : nullptr;
+      }
+      w.stamps = c->stamps ? c->dbg + 4 * c->bmax + kDbgSigma + 5 + 17 : nullptr;
+      PrepParams prep{};
+      prep.lab = n.lab; prep.pl = n.pl; prep.Nh = n.Nh; prep.Ng = n.Ng; prep.h = h; prep.g = g; prep.s = s; prep.L = L;
+      prep.l2_flag = n.l2_flag; prep.prepB = c->prepB; prep.prepG = c->prepG;
+      prof_begin(c);
+      n.prep_ready = launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream) ? 1 : 0;
+      if (n.fused) n.wait_count = n.nred + (n.prep_ready ? 0 : kD * kD);
+      prof_end(c, 1);
+      // ---- reduce (+ all-reduce over the batch shards) -----------------------------------------
+      if (!fused) {
+        prof_begin(c);
+        launch_reduce(c->slabs, nblk, c->slab_stride, (int)bsize + kMetricSlots, c->red, c->stream);
+        prof_end(c, 2);
+      }
+      if (c->comm) NCCL_TRY(ncclAllReduce(c->red, c->red, bsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
+      prof_begin(c);
+      { int rc = run_narrow(c, n, npath); if (rc) return rc; }
+      prof_end(c, 3);
+      {   // diagnostic: TNML_EXTRA_LAUNCHES=k adds k trivial dependent launches per step (prices a boundary)
+        static const int extra = getenv("TNML_EXTRA_LAUNCHES") ? atoi(getenv("TNML_EXTRA_LAUNCHES")) : 0;
+        for (int x = 0; x < extra; ++x) launch_scale(c->scal, 1, 1.0f, c->stream);
+      }
+      c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
+      if (mode == 1) {
+        // the behind environment list grew (as update_B does, Network_class.py:637-652); nothing else changes
+        HIP_TRY(hipGetLastError());
+        if (metrics_out) {
+          HIP_TRY(hipMemcpyAsync(metrics_out, c->metrics, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        return TNML_OK;
+      }
     }
     // ---- bookkeeping ---------------------------------------------------------------------------
     int m_kept = m;
@@ -889,7 +1036,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     c->lab_cur ^= 1;
     c->prev_h = h; c->prev_g = g; c->prev_p = p; c->prev_left_dir = left_dir;
     c->Bnew_valid = true;
-    c->f_current = false;
+    c->f_current = pipe;          // the batch-side workgroups of a pipelined launch stored f of this step already
     c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
     if (c->check_launches) HIP_TRY(hipGetLastError());
     if (c->sync_interval > 0 && (step + 1) % c->sync_interval == 0) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -904,7 +1051,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     if (left_dir) c->Rn_valid = false; else c->Ln_valid = false;
   }
   // f from the last updated B (the value sweep_step returns, Network_class.py:573)
-  {
+  if (!c->f_current) {
     WideParams w{};
     w.b = c->b; w.b_pad = c->b_pad; w.L = L;
     fill_prev_operands(c, w, left_dir, c->prev_p);
@@ -921,14 +1068,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
   if (f_out) { int rc = copy_f_out(c, c->f, f_out); if (rc) return rc; }
   if (metrics_out || f_out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    int st = 0;
-    HIP_TRY(hipMemcpy(&st, c->status, sizeof(int), hipMemcpyDeviceToHost));
-    if (st) {
-      HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
-      if (st & 4) return fail(TNML_ERR_STATE, "internal: helper workgroups of a fused step never arrived (status %d)", st);
-      if (st & 1) return fail(TNML_ERR_NONFINITE, "non-finite values reached the bond update / SVD (status %d)", st);
-      return fail(TNML_ERR_NONFINITE, "Jacobi SVD did not converge (status %d)", st);
-    }
+    return check_status(c);
   }
   return TNML_OK;
 }
@@ -1075,13 +1215,7 @@ extern "C" int tnml_svd_split(tnml_ctx *c, const float *mat, int rows, int cols,
     HIP_TRY(hipMemcpy(sg.data(), c->dbg + 4 * bsize, nn * sizeof(double), hipMemcpyDeviceToHost));
     for (int i = 0; i < nn; ++i) sigma[i] = sg[i];
   }
-  int st = 0;
-  HIP_TRY(hipMemcpy(&st, c->status, sizeof(int), hipMemcpyDeviceToHost));
-  if (st) {
-    HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
-    return fail(TNML_ERR_NONFINITE, st & 1 ? "non-finite values reached the SVD" : "Jacobi SVD did not converge");
-  }
-  return TNML_OK;
+  return check_status(c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1116,6 +1250,13 @@ extern "C" int tnml_set_trunc_threshold(tnml_ctx *c, double threshold) {
 extern "C" int tnml_set_narrow_path(tnml_ctx *c, int force_large) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   c->force_big = force_large != 0;
+  return TNML_OK;
+}
+
+extern "C" int tnml_set_step_pipeline(tnml_ctx *c, int on) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  c->pipe_enabled = on != 0;
+  c->Z_valid = false;
   return TNML_OK;
 }
 

@@ -103,7 +103,17 @@ struct NarrowParams {
   int *m_out;              // device int receiving the kept rank (adaptive truncation), may be nullptr
   double chol_thr;         // > 0: one pivoted-Cholesky step before the Jacobi iteration when off(G) / trace(G) exceeds it
   double svd_stop2;        // Jacobi stops after a sweep whose rotations all had g^2 / scale^2 <= svd_stop2 (tnml_set_svd_stop)
-  int *status;             // device status word: bit0 non-finite, bit1 jacobi not converged
+  int *status;             // device status word: bit0 non-finite, bit1 jacobi not converged, bit2 helpers late, bit3 flag never seen
+  int wait_count;          // fused / pipelined launch: helper arrivals workgroup 0 waits for on `sync`
+  // pipelined step (wide_pipe_device.h): the raw gradient is A_{k-1}^T . Z_k, Z_k reduced by the previous launch
+  int pipe;                // 1: `zred` replaces `red`
+  int z_first;             // first step of a sweep: Z_0 is the gradient itself
+  int z_rows;              // h_{k-1} * D
+  int zsize;               // elements of Z_k (the metric tail follows)
+  const float *zred;
+  CoreView zcore;          // A_{k-1}(h_{k-1}, d, h_k)
+  unsigned *flag;          // if set: B_new is stored with agent-scope stores and `token` is written here afterwards
+  unsigned token;
 };
 
 struct NormChainSite {
@@ -130,7 +140,7 @@ struct PrepParams {
 bool launch_wide(const WideParams &p, int nblk, const PrepParams *prep, hipStream_t st);
 void launch_f_only(const WideParams &p, int nblk, hipStream_t st);
 void launch_reduce(const float *slabs, int nblk, int slab_stride, int n, float *red, hipStream_t st);
-void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st);   // grid = p.fused ? 1 + p.nred + 4 : 1
+void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st);   // grid = p.fused ? 1 + p.wait_count : 1
 // Large-tensor path of the same step (kernels_big.hip): HBM scratch, n = min(rows, cols) <= 128.
 struct BigScratch {
   float *Bf;          // [bmax]   merged tensor

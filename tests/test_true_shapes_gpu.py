@@ -109,43 +109,88 @@ def test_large_bond_goldens(name, large):
 # ---------------------------------------------------------------------------------------------------------------
 # C2 / C3 at their true shape
 # ---------------------------------------------------------------------------------------------------------------
+def resync(st, ctx, left):
+    """Hand the device's state to the oracle: cores (float32 -> float64), bonds, label position and the one behind
+    environment the next oracle step grows from.  The sweep dynamics amplifies float32 rounding (the loss derivative
+    1 / (fa - 1 + 1e-4) has a pole at saturated outputs: a float64 oracle whose cores are rounded to float32 after every
+    step drifts from the plain one by 1e-2 within a dozen steps near the chain end), so long
+    free-running comparisons measure that amplification, not the kernels: the oracle is re-based on the device's
+    state every `chunk` steps and each chunk is compared on its own."""
+    cores_d, bond_d, lp = ctx.get_cores()
+    st.cores = [c.astype(np.float64) for c in cores_d]
+    st.bond = [int(v) for v in bond_d]
+    st.l_pos = int(lp)
+    st.Ln, st.Rn = {}, {}
+    p = lp - 1 if left else lp
+    if not left and p - 2 >= 0:
+        st.Lenv[p - 2] = ctx.get_env(hip().SIDE_LEFT, p - 2).astype(np.float64)
+    if left and p + 3 <= st.N - 1:
+        st.Renv[p + 3] = ctx.get_env(hip().SIDE_RIGHT, p + 3).astype(np.float64)
+
+
 @pytest.mark.parametrize('cfg,N,M,b,L', [('c2', 784, 10, 1000, 2), ('c3', 784, 20, 5000, 2)])
 def test_bench_config_true_shape(cfg, N, M, b, L):
+    """Sweep 1 (right, from the calibrated random start): device and oracle free-running over all 783 steps.
+    Sweep 2 (left): the same in chunks of 29 steps, the oracle re-based on the device's cores between chunks."""
     D = 2
+    chunk = 29
+    assert (N - 1) % chunk == 0
     X, y = synth(N, b, L, 1234)
     X64 = X.astype(np.float64)
+    y1h = mo.one_hot(y, L)
     t0 = time.time()
     st, cores32 = calibrated_pair(N, M, D, L, X, 99)
     ctx = hip().Context(N, D, L, M, b)
     ctx.set_cores(cores32, 0)
     ctx.set_input(X, y)
+    hp = (HP['lr'], HP['weight_dec'], True, HP['act_fn'], HP['loss_fn'], HP['T'], 'fixed')
+    okw = dict(L2_flag=True, act_fn=HP['act_fn'], loss_fn=HP['loss_fn'], T=HP['T'], trunc='fixed')
     obs = {}
-    for sw in range(2):
-        f_o = mo.forward(st, X64)
-        f_d = ctx.forward()
-        obs['fwd%d' % sw] = relerr(f_d, f_o)
-        left = st.l_pos == N - 1
-        vh = [[], []]
-        f_o = mo.sweep(st, X64, y, f_o, HP['lr'], HP['weight_dec'], L2_flag=True, left_dir=left, var_hist=vh,
-                       act_fn=HP['act_fn'], loss_fn=HP['loss_fn'], T=HP['T'], trunc='fixed')
-        met, f_d = ctx.sweep(left, N - 1, True, HP['lr'], HP['weight_dec'], True, HP['act_fn'], HP['loss_fn'], HP['T'], 'fixed')
-        obs['f%d' % sw] = relerr(f_d, f_o)
-        obs['acc%d' % sw] = float(np.abs(met[:, 0] - np.array(vh[0])).max())
-        obs['mae%d' % sw] = float(np.abs(met[:, 1] - np.array(vh[1])).max())
-        _, bond_d, lp = ctx.get_cores()
-        assert list(bond_d) == list(st.bond) and lp == st.l_pos
-        assert max(bond_d) == M and int(np.sum(np.asarray(bond_d) == M)) >= N - 1 - 2 * 6
+    # ---- sweep 1: free-running
+    f_o = mo.forward(st, X64)
+    obs['fwd0'] = relerr(ctx.forward(), f_o)
+    vh = [[], []]
+    f_o = mo.sweep(st, X64, y, f_o, HP['lr'], HP['weight_dec'], left_dir=False, var_hist=vh, **okw)
+    met, f_d = ctx.sweep(False, N - 1, True, *hp)
+    obs['f0'] = relerr(f_d, f_o)
+    obs['acc0'] = float(np.abs(met[:, 0] - np.array(vh[0])).max())
+    obs['mae0'] = float(np.abs(met[:, 1] - np.array(vh[1])).max())
+    _, bond_d, lp = ctx.get_cores()
+    assert list(bond_d) == list(st.bond) and lp == st.l_pos == N - 1
+    assert max(bond_d) == M and int(np.sum(np.asarray(bond_d) == M)) >= N - 1 - 2 * 6
+    # ---- sweep 2: chunks, oracle re-based on the device between them
+    resync(st, ctx, True)
+    f_o = mo.forward(st, X64)
+    obs['fwd1'] = relerr(ctx.forward(), f_o)
+    st.Renv = {}
+    errs, acc_gap, mae_gap = [], 0.0, 0.0
+    for c0 in range(0, N - 1, chunk):
+        accs, maes = [], []
+        for j in range(chunk):
+            rec = {}
+            f_o = mo.sweep_step(st, f_o, y1h, HP['lr'], HP['weight_dec'], left_dir=True, record=rec, **okw)
+            accs.append(rec['accuracy']); maes.append(rec['MAE'])
+        met, f_d = ctx.sweep(True, chunk, c0 == 0, *hp)
+        errs.append(relerr(f_d, f_o))
+        acc_gap = max(acc_gap, float(np.abs(met[:, 0] - np.array(accs)).max()))
+        mae_gap = max(mae_gap, float(np.abs(met[:, 1] - np.array(maes)).max()))
+        assert list(ctx.get_cores()[1]) == list(st.bond)
+        resync(st, ctx, True)
+        f_o = f_d.astype(np.float64)
+    obs['f1_worst_chunk'], obs['f1_median_chunk'] = float(np.max(errs)), float(np.median(errs))
+    obs['acc1'], obs['mae1'] = acc_gap, mae_gap
+    assert ctx.l_pos == st.l_pos == 0
     X2, _ = synth(N, b, L, 4321)
     ctx.set_input(X2, y)
     obs['fresh'] = relerr(ctx.forward(), mo.forward(st, X2.astype(np.float64)))
     ctx.close()
     print(cfg, 'true shape', {k: '%.2e' % v for k, v in obs.items()}, '%.0f s' % (time.time() - t0))
-    for sw in range(2):
-        assert obs['fwd%d' % sw] < 5e-3
-        assert obs['f%d' % sw] < 1e-2             # 783 float32 steps against float64
-        assert obs['acc%d' % sw] <= 3.0 / b + 1e-6   # a borderline sample may flip its argmax in float32
-        assert obs['mae%d' % sw] < 2e-3
-    assert obs['fresh'] < 1e-2
+    assert obs['fwd0'] < 1e-4 and obs['fwd1'] < 1e-4        # observed 8e-8 / 1e-5
+    assert obs['f0'] < 2e-3                                  # observed 1e-5 over 783 free-running steps
+    assert obs['acc0'] <= 1.0 / b + 1e-6 and obs['mae0'] < 1e-4
+    assert obs['f1_median_chunk'] < 5e-4 and obs['f1_worst_chunk'] < 3e-2
+    assert obs['acc1'] <= 3.0 / b + 1e-6 and obs['mae1'] < 2e-3
+    assert obs['fresh'] < 1e-4                               # same cores on both sides
 
 
 # ---------------------------------------------------------------------------------------------------------------
