@@ -3,16 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-One bench "step" = one pass of the hot path over one resident batch = what Network.train does per
-batch (Network_class.py:327-333): forward (environment build) + one sweep of N-1 two-site steps.
-Consecutive passes alternate sweep direction, as training does.  `value` = sweep steps per second
-over the whole job: K * (N-1) * n_gpus_factor / wall time, inputs resident in HBM.
+One bench "step" = one training pass of the hot path = what Network.train does per batch (Network_class.py:324-333):
+a NEW batch becomes resident, forward (environment build), one sweep of N-1 two-site steps; consecutive passes
+alternate sweep direction.  The passes cycle through `--batches` (default 4) distinct synthetic batches that were staged
+in HBM before the timed region (tnml_stage_batch); inside the timed region a pass starts with the device-side hand-over
+of its batch (tnml_select_batch: re-tiling + label copy, no host traffic).  `value` = sweep steps per second over the
+whole job, inputs resident in HBM, barrier + device synchronisation on both sides, max over ranks.
 
-Workload (BASELINE.json configs[2]): N = 784 sites, D = 2, L = 2, bond 20,
-batch 5000 per GPU (weak scaling: every rank sweeps its own 5000-sample shard and the bond gradient
-is all-reduced over RCCL each step), softmax + full_cross_ent, T = 0.1, lr = 1e-3, wd = 1e-3 with
-the L2 norm-environment regulariser on (the reference's default), fixed-bond truncation (the only
-policy under which "bond 20" exists).  Synthetic pixels, 81 % zeros.
+Workload (BASELINE.json configs[2]): N = 784 sites, D = 2, L = 2, bond 20, batch 5000 per GPU,
+softmax + full_cross_ent, T = 0.1, lr = 1e-3, wd = 1e-3 with the L2 norm-environment regulariser on (the reference's
+default), fixed-bond truncation (the only policy under which "bond 20" exists).  Synthetic pixels,
+81 % zeros.  --config c4 is the fixed global batch of 20000 split over the ranks (strong scaling).
 
 Prints ONE JSON line on rank 0.
 """
@@ -28,13 +29,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (N, M, b_per_gpu, L)
-    'c2': (784, 10, 1000, 2),
-    'c3': (784, 20, 5000, 2),
-    'c4': (784, 20, 2500, 2),     # per-GPU share of batch 20000 over 8 GPUs (run with --gpus 8)
-    'c5': (784, 50, 5000, 10),    # ten labels, bond 50: the large-tensor path of the step (kernels_big.hip)
+    # name: (N, M, batch, L, batch_is_global)
+    'c2': (784, 10, 1000, 2, False),
+    'c3': (784, 20, 5000, 2, False),
+    'c4': (784, 20, 20000, 2, True),    # BASELINE.json configs[3]: batch 20000 sharded over the ranks (8 in the baseline)
+    'c5': (784, 50, 5000, 10, False),   # ten labels, bond 50: the large-tensor path of the step (kernels_big.hip)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3
 
 
 def synth(N, b, L, seed):
@@ -57,8 +59,27 @@ def bytes_per_step(b, M, D, L):
     return 4 * b * (3 * M + 3 * D + 2 * L + 1)
 
 
+def flops_per_step(b, M, D, L):
+    # dB GEMM + f GEMM + environment extension
+    return 4.0 * b * D * D * M * M * L + 2.0 * b * D * M * M
+
+
+def host_threads():
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:
+        ncpu = os.cpu_count()
+    blas = None
+    try:                                   # threads NumPy's BLAS actually runs the einsum / matmul calls on
+        from threadpoolctl import threadpool_info
+        blas = max([int(i.get('num_threads', 1)) for i in threadpool_info()] or [1])
+    except Exception:
+        pass
+    return ncpu, blas
+
+
 def cpu_baseline(N, M, D, L, b, n_steps, seed):
-    """The float64 oracle (einsum/BLAS form with cached norm environments) timed on this host:
+    """B4 of BASELINE.md: the float64 oracle (einsum/BLAS form with cached norm environments) timed on this host:
     one forward on the full batch + n_steps sweep steps; rate = (N-1) / (t_fwd + (N-1) t_step)."""
     from oracle import mps_oracle as mo
     X, y = synth(N, b, L, seed)
@@ -72,14 +93,45 @@ def cpu_baseline(N, M, D, L, b, n_steps, seed):
     t_fwd = time.perf_counter() - t0
     y1h = mo.one_hot(y, L)
     st.Lenv = {}
-    # first step builds the norm-environment cache; time steady-state steps after it
-    f = mo.sweep_step(st, f, y1h, 1e-3, 1e-3, True, False, 'softmax', 'full_cross_ent', 0.1, 'fixed')
+    hp = (1e-3, 1e-3, True, False, 'softmax', 'full_cross_ent', 0.1, 'fixed')
+    for _ in range(8):          # past the ramp of the behind bond (1, 2, 4, 8, 16, 20): steady mid-chain steps
+        f = mo.sweep_step(st, f, y1h, *hp)
     t0 = time.perf_counter()
     for _ in range(n_steps):
-        f = mo.sweep_step(st, f, y1h, 1e-3, 1e-3, True, False, 'softmax', 'full_cross_ent', 0.1, 'fixed')
+        f = mo.sweep_step(st, f, y1h, *hp)
     t_step = (time.perf_counter() - t0) / n_steps
     rate = (N - 1) / (t_fwd + (N - 1) * t_step)
-    return rate, t_fwd, t_step
+    return rate, t_fwd, t_step, st, f, X, y1h
+
+
+def cpu_baseline_reference_form(N, M, D, L, st, f, y1h, budget_s):
+    """B1 / B2 / B3 of BASELINE.md section 3: the step in the reference's own computational form
+    (oracle/mps_reference_form.py: broadcast-multiply-sum contractions, L2 norm environments rebuilt from the chain ends
+    at every step, float64), continued from the mid-chain state the B4 timing left behind.  A few steps each, bounded by
+    `budget_s` seconds in total; rates are sweep steps per second of the step alone (the reference's forward, 84-112 s at
+    this shape in the survey container, is not included)."""
+    import copy
+    from oracle import mps_reference_form as rf
+    out = {}
+    t_end = time.perf_counter() + budget_s
+    for tag, trunc, l2 in (('B3_fixed_bond_L2', 'fixed', True), ('B1_reference_truncation_L2', 'reference', True),
+                           ('B2_reference_truncation_noL2', 'reference', False)):
+        s2 = copy.deepcopy(st)
+        s2.Ln, s2.Rn = {}, {}
+        ff = f.copy()
+        times = []
+        for i in range(4):
+            if time.perf_counter() > t_end and times:
+                break
+            t0 = time.perf_counter()
+            ff = rf.sweep_step(s2, ff, y1h, 1e-3, 1e-3, l2, False, 'softmax', 'full_cross_ent', 0.1, trunc)
+            times.append(time.perf_counter() - t0)
+        # the first step of the reference-truncation variants still sees the fixed-bond state (behind bond 20); from the
+        # second on the behind bond is the reference's 2
+        use = times[1:] if len(times) > 1 else times
+        out[tag] = {'steps_per_s': 1.0 / float(np.mean(use)), 'ms_per_step': 1e3 * float(np.mean(use)), 'steps_timed': len(use),
+                    'behind_bond': int(s2.ml(s2.l_pos)), 'ahead_bond': int(s2.mr(min(s2.l_pos + 1, N - 1)))}
+    return out
 
 
 def main():
@@ -90,10 +142,14 @@ def main():
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--policy', default='fixed', choices=['fixed', 'reference'])
     ap.add_argument('--no-l2', action='store_true', help='weight decay as wd*B instead of the L2 norm term')
+    ap.add_argument('--batches', type=int, default=4, help='distinct staged batches the passes cycle through (1: one resident batch)')
     ap.add_argument('--cpu-steps', type=int, default=40, help='oracle steps timed for cpu_baseline (0 = skip)')
+    ap.add_argument('--ref-form-budget', type=float, default=25.0, help='seconds for cpu_baseline_reference_form (0 = skip)')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--svd-stop', type=float, default=None, help='Jacobi stopping threshold (tnml_set_svd_stop); default: the library default')
     ap.add_argument('--no-cold', action='store_true', help='skip the re-initialised (cold start) passes')
+    ap.add_argument('--no-resident', action='store_true', help='skip the secondary single-resident-batch measurement')
+    ap.add_argument('--classic', action='store_true', help='classic launch sequence instead of the pipelined single-launch step')
     ap.add_argument('--sync-interval', type=int, default=0, help='drain the stream every so many sweep steps (runs under rocprofv3 --pmc)')
     ap.add_argument('--check-launches', action='store_true', help='read the launch status back after every kernel launch')
     args = ap.parse_args()
@@ -101,16 +157,16 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if rank == 0:
-            print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
-    N, M, b, L = CONFIGS[args.config]
+    if world != args.gpus and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    N, M, b_cfg, L, is_global = CONFIGS[args.config]
+    b = b_cfg // world if is_global else b_cfg          # per-rank shard
     D = 2
 
     from tensornetworkforml_amd import _hip, dist as tdist
     dist = None
     if world > 1:
-        dist = tdist.init_process_group(rank, world, 'gloo')     # rendezvous only; the data path is RCCL
+        dist = tdist.init_process_group(rank, world)     # rendezvous only; the data path is RCCL
     if _hip.device_count() <= local_rank:
         raise SystemExit('bench.py needs a gfx950 GPU per rank (visible: %d)' % _hip.device_count())
     ctx = _hip.Context(N, D, L, M, b, device=local_rank)
@@ -121,53 +177,71 @@ def main():
         ctx.set_sync_interval(args.sync_interval)
     if args.check_launches:
         ctx.debug_enable(4)
+    if args.classic:
+        ctx.set_step_pipeline(False)
 
-    X, y = synth(N, b, L, 1234 + rank)          # every rank owns a different shard
+    nb = max(1, min(args.batches, 8))
+    batches = [synth(N, b, L, 1234 + 97 * k + rank) for k in range(nb)]     # every rank owns different shards
+    for k, (Xk, yk) in enumerate(batches):
+        ctx.stage_batch(k, Xk, yk)
     cores = init_cores(N, M, D, L, 99)            # same cores on every rank
-    ctx.set_input(X, y)
+    ctx.select_batch(0)
 
     def init_network():
         ctx.set_cores(cores, 0)
-        # calibration on the same batch (Network_class.py:168-176); log-domain: max|f| ~ 1e-66 before it
+        # calibration on the first batch (Network_class.py:168-176); log-domain: max|f| ~ 1e-66 before it
         F2 = float(np.exp(ctx.forward_logabsmax() / N))
         ctx.scale_cores(1.0 / F2)
 
     init_network()
-
     hp = dict(lr=1e-3, weight_dec=1e-3, L2_flag=not args.no_l2, act_fn='softmax', loss_fn='full_cross_ent', T=0.1,
               trunc=args.policy)
+    counter = [0]
 
-    def one_pass(want=False):
+    def one_pass(want=False, rotate=True):
+        if rotate and nb > 1:
+            ctx.select_batch(counter[0] % nb)
+            counter[0] += 1
         ctx.forward(want_f=False)
         left_dir = ctx.l_pos == N - 1
         return ctx.sweep(left_dir, N - 1, True, hp['lr'], hp['weight_dec'], hp['L2_flag'], hp['act_fn'],
                          hp['loss_fn'], hp['T'], hp['trunc'], want_metrics=want, want_f=want)
 
     def barrier():
-        ctx.synchronize()
+        ctx.synchronize()          # also reads the device status word: a failed SVD inside the passes raises here
         if dist is not None:
             dist.barrier()
         ctx.synchronize()
 
+    def timed(n_pass, **kw):
+        barrier()
+        ctx.svd_stats(reset=True)
+        ctx.profile_reset()
+        ctx.profile_enable(2)      # one event pair per sweep call on the library's stream; nothing waits inside
+        t0 = time.perf_counter()
+        for _ in range(n_pass):
+            one_pass(**kw)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dt = dist.max_float(dt)
+        sweep_ms, n_launch = ctx.profile_get(4)
+        _, n_steps_pipe = ctx.profile_get(5)
+        ctx.profile_enable(0)
+        sw_tot, n_svd, rounds_tot = ctx.svd_stats(reset=True)
+        return dict(dt=dt, sweep_ms=sweep_ms, launches=n_launch, pipe_steps=n_steps_pipe,
+                    sweeps_per_svd=sw_tot / max(n_svd, 1), rounds_per_svd=rounds_tot / max(n_svd, 1))
+
     for _ in range(args.warmup):
         one_pass()
-    barrier()
-    ctx.svd_stats(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_pass()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    main_run = timed(args.steps)
+    dt = main_run['dt']
 
-    sw_tot, n_svd, rounds_tot = ctx.svd_stats(reset=True)
-    # SURVEY.md 8.4 break-down: the environment build (forward) and the host -> device hand-over of one batch
-    # on their own, and the rate of the sweep alone
+    # SURVEY.md 8.4 break-down: the environment build (forward) and the host -> device hand-over of one batch on their own
     ctx.synchronize()
+    ctx.timer_start()
+    ctx.select_batch(0)
+    sel_ms = ctx.timer_stop()
     ctx.timer_start()
     ctx.forward(want_f=False)
     fwd_ms = ctx.timer_stop()
@@ -176,7 +250,7 @@ def main():
               hp['trunc'], want_metrics=False, want_f=False)
     ctx.synchronize()
     t0 = time.perf_counter()
-    ctx.set_input(X, y)
+    ctx.set_input(*batches[0])
     ctx.synchronize()
     h2d_ms = 1e3 * (time.perf_counter() - t0)
     # validity: one more pass handing back metrics and f; non-finite values raise inside the library
@@ -184,12 +258,15 @@ def main():
     finite = bool(np.isfinite(f).all() and np.isfinite(met).all())
 
     sweep_steps = args.steps * (N - 1)
-    # weak scaling: every rank performs the same sweep steps on its own shard of b samples, so the job's work unit is
-    # "one sweep step over one b-sample shard" and the whole-job aggregate is world x the common step rate
-    steps_per_s = sweep_steps * 1.0 / dt
-    value = world * steps_per_s
+    steps_per_s = sweep_steps / dt
+    strong = is_global
+    # weak scaling (default): every rank performs the same sweep steps on its own b-sample shard, the job's work unit is
+    # "one sweep step over one shard" and the whole-job aggregate is world x the common step rate.  c4 (strong): the global
+    # batch is fixed, the job performs `steps_per_s` sweep steps per second on it whatever the rank count.
+    value = steps_per_s if strong else world * steps_per_s
+    bstep = bytes_per_step(b, M, D, L)
     out = {
-        'metric': 'sweep-steps/sec, 28x28 MNIST-shaped, bond=%d, batch=%d per GPU' % (M, b),
+        'metric': 'sweep-steps/sec, 28x28 MNIST-shaped, bond=%d, batch=%d%s' % (M, b_cfg, ' (global)' if strong else ' per GPU'),
         'value': value,
         'unit': 'sweep-steps/s',
         'n_gpus': world,
@@ -197,121 +274,143 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps,
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': 'strong' if strong else 'weak',
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': '%s: N=784 sites, D=2, L=%d, bond %d, batch %d/GPU, softmax+full_cross_ent, '
-                               'trunc=%s, L2_flag=%s; pass = forward + %d-step sweep'
-                               % (args.config, L, M, b, args.policy, hp['L2_flag'], N - 1),
-                   'global_batch': b * world, 'sweep_steps_per_pass': N - 1, 'parallelism': 'dp%d' % world},
-        'value_definition': 'sweep steps per second x number of %d-sample shards (= GPUs) stepping in lock-step; '
-                            'global-batch sweep steps per second: %.1f' % (b, steps_per_s),
+        'config': {'workload': '%s: N=784 sites, D=2, L=%d, bond %d, batch %d/GPU, softmax+full_cross_ent, trunc=%s, L2_flag=%s; '
+                               'pass = hand-over of one of %d staged batches + forward + %d-step sweep%s'
+                               % (args.config, L, M, b, args.policy, hp['L2_flag'], nb, N - 1, ' (classic launch sequence)' if args.classic else ''),
+                   'global_batch': b * world, 'sweep_steps_per_pass': N - 1, 'parallelism': 'dp%d' % world,
+                   'distinct_batches': nb},
+        'value_definition': ('global-batch (%d) sweep steps per second' % (b * world)) if strong else
+                            ('sweep steps per second x number of %d-sample shards (= GPUs) stepping in lock-step; common step '
+                             'rate (= sweep steps per second on the global batch of %d): %.1f' % (b, b * world, steps_per_s)),
+        'global_batch_steps_per_s': steps_per_s,
+        'weak_scaling_aggregate': world * steps_per_s,
         'finite': finite,
-        'breakdown': {'forward_ms': fwd_ms, 'h2d_batch_ms': h2d_ms,
-                      'sweep_only_steps_per_s': (N - 1) / max(1e-3 * (1e3 * dt / args.steps - fwd_ms), 1e-9),
+        'breakdown': {'forward_ms': fwd_ms, 'select_batch_ms': sel_ms, 'h2d_batch_ms': h2d_ms,
+                      'sweep_only_steps_per_s': sweep_steps / max(1e-3 * main_run['sweep_ms'], 1e-9),
                       'steps_per_s_incl_h2d': (N - 1) / (dt / args.steps + 1e-3 * h2d_ms)},
         'final_accuracy': float(met[-1, 0]),
         # the SVD is iterative: how much work the timed passes actually contained
-        'jacobi': {'sweeps_per_svd': sw_tot / max(n_svd, 1), 'rounds_per_svd': rounds_tot / max(n_svd, 1),
+        'jacobi': {'sweeps_per_svd': main_run['sweeps_per_svd'], 'rounds_per_svd': main_run['rounds_per_svd'],
                    'svd_stop2': args.svd_stop if args.svd_stop is not None else 1e-6},
     }
 
+    # ---- roofline of the dominant kernel, measured live over the timed region ------------------------------------------------
+    # Pipelined step: one launch of step_pipe_kernel per sweep step carries the whole step (update + SVD of step k next to f /
+    # pre-gradient of step k+1), so it is the dominant kernel and its average duration is the device time of the timed
+    # sweeps (HIP events on the library's stream, first to last launch of each sweep) / launches.  Classic sequence and the
+    # large-tensor path (c5): several kernels per step; the figure is then the whole step per launch group.
+    step_launches = main_run['pipe_steps'] if main_run['pipe_steps'] else sweep_steps
+    step_us = 1e3 * main_run['sweep_ms'] / max(step_launches, 1)
+    if args.config == 'c5':
+        fl = flops_per_step(b, M, D, L)
+        tf = fl / (step_us * 1e-6) / 1e12
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'sweep step (wide_step_mfma_tiled_kernel + large-tensor chain; pipelined launches at the chain ends)',
+                           'achieved': tf, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF, 'traffic': None,
+                           'algorithmic_flops_per_step': fl, 'algorithmic_bytes_per_step': bstep, 'step_avg_us_hip_events': step_us}
+    else:
+        ach = bstep / (step_us * 1e-6) / 1e9
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'step_pipe_kernel' if main_run['pipe_steps'] else 'wide_step_mfma_kernel + narrow_step_kernel',
+                           'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                           'algorithmic_bytes_per_launch': bstep, 'kernel_avg_us_hip_events': step_us, 'launches_timed': step_launches,
+                           'note': 'one launch = one whole sweep step; the step is bound by the sequential SVD of its merged tensor '
+                                   '(critical_path below), not by HBM'}
+        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_%s.json' % args.config)
+        if os.path.exists(pmc) and args.policy == 'fixed' and not args.no_l2 and not args.classic:
+            w = json.load(open(pmc)).get('step_pipe_kernel', {})
+            if 'FETCH_SIZE' in w and 'WRITE_SIZE' in w:
+                # gfx950: FETCH_SIZE counts half of a coalesced read stream (MI355X_MICROARCH.md, HBM section)
+                out['roofline']['traffic_from_profiles'] = {
+                    'bytes_per_launch': (2.0 * w['FETCH_SIZE']['mean_KB'] + w['WRITE_SIZE']['mean_KB']) * 1024.0,
+                    'source': 'profiles/r02_pmc_%s.json (separate rocprofv3 --pmc passes, not this run)' % args.config}
+
     if rank == 0 and not args.no_kernel_profile:
-        # per-kernel device time with HIP events on the library's own stream (two more passes)
+        # per-kernel device time with HIP events around every launch (two more passes; synchronises after each launch)
         ctx.profile_reset()
-        ctx.profile_enable(True)
+        ctx.profile_enable(1)
         one_pass()
         one_pass()
-        ctx.profile_enable(False)
-        # the wide kernel is the one-shot MFMA formulation whenever its tile operands fit LDS (all configs but c5, which
-        # streams the merged tensor through LDS in chunks); on one GPU
-        # the slab reduction rides inside the narrow launch (helper workgroups), so reduce_slabs_kernel shows 0 launches
-        wide_name = 'wide_step_mfma_tiled_kernel' if args.config == 'c5' else 'wide_step_mfma_kernel'
-        names = ['env_chain_kernel', wide_name, 'reduce_slabs_kernel', 'narrow_step_kernel']
+        ctx.profile_enable(0)
+        names = ['env_chain_kernel', 'batch-side kernel (classic wide kernel / prologue of a pipelined sweep)', 'reduce_slabs_kernel',
+                 'step kernel (step_pipe_kernel, or the classic narrow kernel / large-tensor chain)']
         kern = {}
         for i, nm in enumerate(names):
             ms, n = ctx.profile_get(i)
             kern[nm] = {'avg_us': 1e3 * ms / max(n, 1), 'launches': n, 'total_ms': ms}
         out['kernels'] = kern
-        bstep = bytes_per_step(b, M, D, L)
-        wide_us = kern[wide_name]['avg_us']
-        ach = bstep / (wide_us * 1e-6) / 1e9
-        # HBM traffic of that kernel from committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
-        # runs of this command; gfx950 correction: FETCH_SIZE counts half of a coalesced read stream)
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_%s.json' % args.config)
-        if os.path.exists(pmc) and args.policy == 'fixed' and not args.no_l2:
-            w = json.load(open(pmc)).get(wide_name, {})
-            if 'FETCH_SIZE' in w and 'WRITE_SIZE' in w:
-                traffic = (2.0 * w['FETCH_SIZE']['mean_KB'] + w['WRITE_SIZE']['mean_KB']) * 1024.0
-        # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary of this command (the HIP
-        # event figure above brackets one isolated launch and carries its ~3 us of launch latency)
-        rocprof_us = None
-        kst = os.path.join(ROOT, 'profiles', 'r01_kernel_stats_%s.csv' % args.config)
-        if os.path.exists(kst) and args.policy == 'fixed' and not args.no_l2:     # the summary is of the default case
-            import csv
-            for row in csv.DictReader(open(kst)):
-                if wide_name + '(' in row['Name'] or row['Name'].split('(')[0].endswith(wide_name):
-                    rocprof_us = float(row['AverageNs']) / 1e3
-        flops_step = 4.0 * b * D * D * M * M * L + 2.0 * b * D * M * M      # dB GEMM + f GEMM + env extension
-        if args.config == 'c5':
-            # bond 50 / ten labels is the MFMA-bound case (580 flop per algorithmic byte); float32 MFMA peak of
-            # MI355X_MICROARCH.md: 157.3 TFLOP/s (v_mfma_f32_16x16x4_f32 runs at the float32 vector rate)
-            tf = flops_step / (wide_us * 1e-6) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': wide_name, 'achieved': tf, 'peak': 157.3, 'unit': 'TFLOP/s',
-                               'frac': tf / 157.3, 'traffic': None, 'algorithmic_flops_per_launch': flops_step,
-                               'algorithmic_bytes_per_launch': bstep, 'kernel_avg_us_hip_events': wide_us,
-                               'kernel_avg_us_rocprofv3': None}
-        else:
-            out['roofline'] = {'bound': 'hbm', 'kernel': wide_name, 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                               'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                               'algorithmic_bytes_per_launch': bstep, 'kernel_avg_us_hip_events': wide_us,
-                               'kernel_avg_us_rocprofv3': rocprof_us,
-                               'whole_step_GBs': bstep * steps_per_s / 1e9}
+        # critical path of the update + SVD workgroup of a mid-chain step, from its in-kernel cycle stamps
+        try:
+            ctx.debug_enable(2)
+            ctx.forward(want_f=False)
+            left_dir = ctx.l_pos == N - 1
+            ctx.sweep(left_dir, (N - 1) // 2, True, hp['lr'], hp['weight_dec'], hp['L2_flag'], hp['act_fn'], hp['loss_fn'], hp['T'],
+                      hp['trunc'], want_metrics=False, want_f=False)
+            ctx.synchronize()
+            sc = ctx.step_debug('scalars')
+            ctx.sweep(left_dir, N - 1 - (N - 1) // 2, False, hp['lr'], hp['weight_dec'], hp['L2_flag'], hp['act_fn'], hp['loss_fn'],
+                      hp['T'], hp['trunc'], want_metrics=False, want_f=False)
+            ctx.debug_enable(0 if not args.check_launches else 4)
+            if sc[10] > 1:
+                rounds = sc[9] * (sc[10] - 1)
+                out['critical_path'] = {'what': 'workgroup 0 of one mid-chain step (shader cycles from s_memtime stamps)',
+                                        'cycles_before_svd': sc[5], 'cycles_jacobi': sc[6], 'cycles_after_svd': sc[7],
+                                        'jacobi_sweeps': sc[9], 'matrix_side': sc[10], 'rounds': rounds,
+                                        'cycles_per_round': sc[6] / max(rounds, 1),
+                                        'kernel_us_realtime_counter': sc[8] / 100.0,
+                                        'clock_GHz': (sc[5] + sc[6] + sc[7]) / max(sc[8] * 10.0, 1e-9)}
+        except Exception as e:      # the stamps are diagnostics: never fail the bench on them
+            out['critical_path'] = {'error': str(e)[:200]}
     elif dist is not None and not args.no_kernel_profile:
         # keep the collectives of the profiling passes matched on every rank
         one_pass()
         one_pass()
+        ctx.forward(want_f=False)
+        left_dir = ctx.l_pos == N - 1
+        ctx.sweep(left_dir, (N - 1) // 2, True, hp['lr'], hp['weight_dec'], hp['L2_flag'], hp['act_fn'], hp['loss_fn'], hp['T'], hp['trunc'],
+                  want_metrics=False, want_f=False)
+        ctx.sweep(left_dir, N - 1 - (N - 1) // 2, False, hp['lr'], hp['weight_dec'], hp['L2_flag'], hp['act_fn'], hp['loss_fn'], hp['T'],
+                  hp['trunc'], want_metrics=False, want_f=False)
+
+    if not args.no_resident and nb > 1:
+        # the round-1 regime for comparison: the same passes on ONE resident batch (the chain converges onto it and the
+        # Jacobi iteration settles at ~2 sweeps per SVD)
+        ctx.select_batch(0)
+        for _ in range(max(args.warmup, 2)):
+            one_pass(rotate=False)
+        r = timed(args.steps, rotate=False)
+        out['resident_batch'] = {'value': (1 if strong else world) * sweep_steps / r['dt'], 'unit': 'sweep-steps/s',
+                                 'jacobi_sweeps_per_svd': r['sweeps_per_svd']}
 
     if not args.no_cold:
-        # "cold" passes: network re-initialised (random cores, calibrated) and swept twice -- the regime
-        # of the first training batches, where the merged tensors are far from their SVD form and the
-        # Jacobi iteration needs its full 7-9 sweeps
+        # "cold" passes: network re-initialised (random cores, calibrated) and swept twice -- the regime of the first
+        # training batches, where the merged tensors are far from their SVD form
+        ctx.select_batch(0)
         init_network()
-        barrier()
-        ctx.svd_stats(reset=True)
-        t0 = time.perf_counter()
-        one_pass()
-        one_pass()
-        barrier()
-        dtc = time.perf_counter() - t0
-        if dist is not None:
-            import torch
-            t = torch.tensor([dtc], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtc = float(t.item())
-        sw_c, n_c, _ = ctx.svd_stats(reset=True)
-        out['cold_start'] = {'value': 2 * (N - 1) / dtc, 'unit': 'sweep-steps/s', 'passes': 2,
-                             'jacobi_sweeps_per_svd': sw_c / max(n_c, 1)}
+        r = timed(2)
+        out['cold_start'] = {'value': (1 if strong else world) * 2 * (N - 1) / r['dt'], 'unit': 'sweep-steps/s', 'passes': 2,
+                             'jacobi_sweeps_per_svd': r['sweeps_per_svd']}
 
     if rank == 0 and args.cpu_steps > 0:
-        rate, t_fwd, t_step = cpu_baseline(N, M, D, L, b, args.cpu_steps, 1234)
-        try:
-            ncpu = len(os.sched_getaffinity(0))
-        except Exception:
-            ncpu = os.cpu_count()
-        blas_threads = None
-        try:                                   # threads NumPy's BLAS actually runs the einsum / matmul calls on
-            from threadpoolctl import threadpool_info
-            blas_threads = max([int(i.get('num_threads', 1)) for i in threadpool_info()] or [1])
-        except Exception:
-            pass
+        rate, t_fwd, t_step, st, fcpu, Xc, y1h = cpu_baseline(N, M, D, L, b, args.cpu_steps, 1234)
+        ncpu, blas_threads = host_threads()
         out['cpu_baseline'] = {'value': rate, 'unit': 'sweep-steps/s', 'cores': blas_threads or ncpu, 'host_cpus': ncpu,
                                'kind': 'port',
-                               'sample': 'float64 NumPy oracle (einsum/BLAS, cached norm environments): 1 forward on '
-                                         'the full %d-sample batch (%.2f s) + %d sweep steps (%.1f ms each), '
+                               'sample': 'float64 NumPy oracle (einsum/BLAS, cached norm environments; B4 of BASELINE.md): 1 forward '
+                                         'on the full %d-sample batch (%.2f s) + %d mid-chain sweep steps (%.1f ms each), '
                                          'extrapolated to a %d-step pass' % (b, t_fwd, args.cpu_steps, 1e3 * t_step, N - 1)}
+        if args.ref_form_budget > 0 and args.config != 'c5':
+            rf = cpu_baseline_reference_form(N, M, D, L, st, fcpu, y1h, args.ref_form_budget)
+            out['cpu_baseline_reference_form'] = {
+                'unit': 'sweep-steps/s', 'cores': 1, 'kind': 'port',
+                'sample': 'the step in the reference\'s own computational form (oracle/mps_reference_form.py: broadcast-multiply-sum '
+                          'contractions, float64, L2 norm environments rebuilt at every step), mid-chain, a few steps each; '
+                          'forward not included',
+                'forms': rf,
+                'gpu_over_B3': steps_per_s / rf['B3_fixed_bond_L2']['steps_per_s'],
+                'gpu_over_B1': steps_per_s / rf['B1_reference_truncation_L2']['steps_per_s']}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -96,6 +96,13 @@ int tnml_scale_cores(tnml_ctx *ctx, double factor);
 /* ---- batch ------------------------------------------------------------------------------ */
 /* X [b][N][D] float32, y [b] int32 (may be NULL when only forward is wanted) */
 int tnml_set_input(tnml_ctx *ctx, const float *X, const int32_t *y, int b);
+/* A data loader that keeps several batches on the device: tnml_stage_batch copies X [b][N][D] and y [b] into device slot
+ * `slot` (0..7, synchronous host -> device copy); tnml_select_batch makes a staged batch the resident one with device-side
+ * work only (re-tiling to the site-major layout, label copy) and without waiting -- the counterpart of tnml_set_input for
+ * inputs that are already in HBM.  No reference analogue (the reference's loaders hand NumPy arrays to forward,
+ * Network_class.py:324-327). */
+int tnml_stage_batch(tnml_ctx *ctx, int slot, const float *X, const int32_t *y, int b);
+int tnml_select_batch(tnml_ctx *ctx, int slot);
 /* labels of the resident batch alone (Network.sweep receives y after forward saw X,
  * Network_class.py:327-333) */
 int tnml_set_labels(tnml_ctx *ctx, const int32_t *y, int b);
@@ -199,9 +206,13 @@ int tnml_batch(tnml_ctx *ctx);
 /* HIP-event timing on the context's own stream (torch.cuda.Event would not see it) */
 int tnml_timer_start(tnml_ctx *ctx);
 int tnml_timer_stop(tnml_ctx *ctx, double *elapsed_ms);
-/* accumulated per-kernel device time (ms) and launch counts since the last reset, measured with
- * HIP events around each launch when profiling is enabled (slows the sweep; bench only)
- *   which: 0 forward chain, 1 wide step kernel, 2 reduce kernel, 3 narrow (update+SVD) kernel */
+/* tnml_profile_enable(ctx, 1): accumulated per-kernel device time (ms) and launch counts since the last reset, measured
+ * with HIP events around each launch (synchronises after every launch: slows the sweep; break-downs only)
+ *   which: 0 forward chain, 1 batch-side kernel (classic wide kernel / prologue of the pipelined step), 2 reduce kernel,
+ *          3 update+SVD kernel (classic narrow kernel / the single launch of a pipelined step)
+ * tnml_profile_enable(ctx, 2): one HIP event pair per tnml_sweep call, nothing waits inside the timed region
+ *   which: 4 -> ms between first and last launch of all sweeps since the reset, launches = kernel launches they made
+ *          5 -> the same ms, launches = number of single-launch (pipelined) steps among them */
 int tnml_profile_enable(tnml_ctx *ctx, int on);
 int tnml_profile_get(tnml_ctx *ctx, int which, double *ms, long long *launches);
 int tnml_profile_reset(tnml_ctx *ctx);

@@ -27,7 +27,7 @@ SYMBOLS = [
     'tnml_get_step_debug', 'tnml_l_pos', 'tnml_batch', 'tnml_timer_start', 'tnml_timer_stop',
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
     'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict', 'tnml_set_trunc_threshold',
-    'tnml_set_sync_interval', 'tnml_set_step_pipeline',
+    'tnml_set_sync_interval', 'tnml_set_step_pipeline', 'tnml_stage_batch', 'tnml_select_batch',
 ]
 
 
@@ -93,6 +93,8 @@ def lib():
         L.tnml_set_trunc_threshold.argtypes = [vp, C.c_double]
         L.tnml_set_sync_interval.argtypes = [vp, C.c_int]
         L.tnml_set_step_pipeline.argtypes = [vp, C.c_int]
+        L.tnml_stage_batch.argtypes = [vp, C.c_int, f32p, i32p, C.c_int]
+        L.tnml_select_batch.argtypes = [vp, C.c_int]
         L.tnml_svd_split.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f64p]
         _lib = L
     return _lib
@@ -196,6 +198,18 @@ class Context:
             yp = _ptr(y, C.c_int32)
         _chk(lib().tnml_set_input(self._h, _ptr(X, C.c_float), yp, X.shape[0]))
         self.b = X.shape[0]
+
+    def stage_batch(self, slot, X, y):
+        """Copy a batch into device slot `slot` (0..7); `select_batch` later makes it resident without host traffic."""
+        X = _f32(X)
+        assert X.ndim == 3 and X.shape[1] == self.N and X.shape[2] == self.D
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        assert y.shape == (X.shape[0],)
+        _chk(lib().tnml_stage_batch(self._h, int(slot), _ptr(X, C.c_float), _ptr(y, C.c_int32), X.shape[0]))
+
+    def select_batch(self, slot):
+        _chk(lib().tnml_select_batch(self._h, int(slot)))
+        self.b = int(lib().tnml_batch(self._h))
 
     def set_labels(self, y):
         y = np.ascontiguousarray(y, dtype=np.int32)
@@ -353,7 +367,8 @@ class Context:
         return ms.value
 
     def profile_enable(self, on=True):
-        _chk(lib().tnml_profile_enable(self._h, int(bool(on))))
+        """True / 1: events around every launch (synchronising); 2: one event pair per sweep call; False / 0: off."""
+        _chk(lib().tnml_profile_enable(self._h, int(on)))
 
     def profile_reset(self):
         _chk(lib().tnml_profile_reset(self._h))

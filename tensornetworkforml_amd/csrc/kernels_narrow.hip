@@ -57,6 +57,7 @@ struct NarrowCarve {
   double *dT, *dG, *Z, *dNh, *dNg, *dLam, *dRed, *dT2, *dCS, *dSq;
   float *fB, *fBp, *sLab, *sPl, *sCb;
   int *sOrd, *sFlag, *sPi, *sPiInv;
+  float *sTail;
   size_t bytes;
 };
 
@@ -88,6 +89,7 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
   k.sFlag = ip; ip += 8;
   k.sPi = ip; ip += ne;
   k.sPiInv = ip; ip += ne;
+  k.sTail = (float *)ip; ip += kMetricSlots;
   k.bytes = (size_t)((unsigned char *)ip - base);
   return k;
 }
@@ -162,7 +164,10 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     return (p.fused && !p.pipe) ? __hip_atomic_load(p.red + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.red[e];
   };
   // metric sums of the batch-side workgroups: behind the gradient (classic) or behind the reduced pre-gradient (pipelined)
-  auto ldtail = [&](int i) -> float { return p.pipe ? p.zred[p.zsize + i] : ldred(p.bsize + i); };
+  // (pipelined: read NOW -- the batch-side workgroups of this launch overwrite zred once B_new is published)
+  if (p.pipe && threadIdx.x == 0)
+    for (int i = 0; i < kMetricSlots; ++i) k.sTail[i] = p.zred[p.zsize + i];      // LDS: the loads complete here
+  auto ldtail = [&](int i) -> float { return p.pipe ? k.sTail[i] : ldred(p.bsize + i); };
   const int r = D * h, c = D * g * L;
   const bool short_rows = (r <= c);
   const int n = short_rows ? r : c, ne = n + (n & 1), len = short_rows ? c : r;

@@ -69,6 +69,18 @@ struct tnml_ctx {
   double trunc_thr = 0.999;                  // adaptive truncation threshold (tensor_svd's default argument)
   double prof_ms[4] = {0, 0, 0, 0};
   long long prof_n[4] = {0, 0, 0, 0};
+  // whole-sweep timing without any synchronisation inside the timed region (tnml_profile_enable(ctx, 2)): one event pair per
+  // tnml_sweep call, read back by tnml_profile_get(which = 4)
+  bool sweep_timing = false;
+  std::vector<hipEvent_t> sweep_ev;          // pairs
+  size_t sweep_ev_used = 0;
+  double sweep_ms = 0;
+  long long sweep_launches = 0, step_launches = 0;
+  // staged batches (tnml_stage_batch / tnml_select_batch): device-resident [b][N][D] inputs + labels
+  static constexpr int kStageSlots = 8;
+  float *stageX[kStageSlots] = {nullptr};
+  int *stageY[kStageSlots] = {nullptr};
+  int stageB[kStageSlots] = {0};
   // device buffers
   size_t core_stride = 0, lab_elems = 0, bmax = 0;
   float *X = nullptr, *Xstage = nullptr;
@@ -252,6 +264,8 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
                   c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2,
                   c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->zslabs, c->gslabs, c->zred, c->pipe_cnt, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
   for (void *p : ptrs) if (p) (void)hipFree(p);
+  for (int i = 0; i < tnml_ctx::kStageSlots; ++i) { if (c->stageX[i]) (void)hipFree(c->stageX[i]); if (c->stageY[i]) (void)hipFree(c->stageY[i]); }
+  for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->pev0) (void)hipEventDestroy(c->pev0);
@@ -432,6 +446,48 @@ extern "C" int tnml_set_input(tnml_ctx *c, const float *X, const int32_t *y, int
   HIP_TRY(hipStreamSynchronize(c->stream));   // X / y host buffers may be released by the caller
   c->have_input = true;
   c->have_labels = (y != nullptr);
+  c->envs_valid_L = c->envs_valid_R = false;
+  c->f_current = false;
+  c->Bnew_valid = false;
+  c->Z_valid = false;
+  return TNML_OK;
+}
+
+extern "C" int tnml_stage_batch(tnml_ctx *c, int slot, const float *X, const int32_t *y, int b) {
+  if (!c || !X || !y) return fail(TNML_ERR_ARG, "NULL argument");
+  if (slot < 0 || slot >= tnml_ctx::kStageSlots) return fail(TNML_ERR_ARG, "slot %d outside [0, %d)", slot, tnml_ctx::kStageSlots);
+  if (b < 1) return fail(TNML_ERR_ARG, "empty batch");
+  for (int i = 0; i < b; ++i)
+    if (y[i] < 0 || y[i] >= c->L) return fail(TNML_ERR_ARG, "label %d of sample %d outside [0, %d)", y[i], i, c->L);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->stageX[slot]) { (void)hipFree(c->stageX[slot]); (void)hipFree(c->stageY[slot]); c->stageX[slot] = nullptr; c->stageY[slot] = nullptr; }
+  HIP_TRY(hipMalloc(&c->stageX[slot], (size_t)b * c->N * c->D * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->stageY[slot], (size_t)b * sizeof(int)));
+  HIP_TRY(hipMemcpy(c->stageX[slot], X, (size_t)b * c->N * c->D * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->stageY[slot], y, (size_t)b * sizeof(int), hipMemcpyHostToDevice));
+  c->stageB[slot] = b;
+  return TNML_OK;
+}
+
+extern "C" int tnml_select_batch(tnml_ctx *c, int slot) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  if (slot < 0 || slot >= tnml_ctx::kStageSlots || !c->stageX[slot]) return fail(TNML_ERR_ARG, "slot %d holds no staged batch", slot);
+  HIP_TRY(hipSetDevice(c->device));
+  const int b = c->stageB[slot];
+  if (b > c->b_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = alloc_batch_buffers(c, b);
+    if (rc != TNML_OK) return rc;
+  }
+  c->b = b;
+  // what tnml_set_input does after its host -> device copy, entirely on the device and without waiting
+  launch_transpose_input(c->stageX[slot], c->X, b, c->b_pad, c->N, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemsetAsync(c->y, 0, (size_t)c->b_pad * sizeof(int), c->stream));
+  HIP_TRY(hipMemcpyAsync(c->y, c->stageY[slot], (size_t)b * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  c->have_input = true;
+  c->have_labels = true;
   c->envs_valid_L = c->envs_valid_R = false;
   c->f_current = false;
   c->Bnew_valid = false;
@@ -836,6 +892,17 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
   float *ahe = left_dir ? c->Lenv : c->Renv;
   double *nbeh = left_dir ? c->Rn : c->Ln;
   double *nahe = left_dir ? c->Ln : c->Rn;
+  hipEvent_t sw_ev1 = nullptr;
+  if (c->sweep_timing && mode == 0) {
+    if (c->sweep_ev_used + 2 > c->sweep_ev.size()) {
+      hipEvent_t a, b2;
+      HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b2));
+      c->sweep_ev.push_back(a); c->sweep_ev.push_back(b2);
+    }
+    HIP_TRY(hipEventRecord(c->sweep_ev[c->sweep_ev_used], c->stream));
+    sw_ev1 = c->sweep_ev[c->sweep_ev_used + 1];
+    c->sweep_ev_used += 2;
+  }
 
   for (int step = 0; step < n_steps; ++step) {
     const int l = c->l_pos;
@@ -934,6 +1001,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
         prof_begin(c);
         launch_step_pipe(none, wpro, wide_pipe_lds_bytes(wpro), c->stream);
         prof_end(c, 1);
+        c->sweep_launches++; c->step_launches++;
         if (c->comm) NCCL_TRY(ncclAllReduce(c->zred, c->zred, wpro.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
         if (wpro.do_f) c->f_current = true;
       }
@@ -950,6 +1018,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       prof_begin(c);
       launch_step_pipe(n, wp, lds, c->stream);
       prof_end(c, 3);
+      c->sweep_launches++; c->step_launches++;
       if (c->comm && wp.do_z) NCCL_TRY(ncclAllReduce(c->zred, c->zred, wp.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
       c->Z_valid = wp.do_z != 0; c->Z_k = k + 1; c->Z_left = left_dir; c->Z_act = act_fn; c->Z_loss = loss_fn; c->Z_T = T;
     } else {
@@ -1009,6 +1078,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       prof_begin(c);
       { int rc = run_narrow(c, n, npath); if (rc) return rc; }
       prof_end(c, 3);
+      c->sweep_launches += (fused ? 2 : 3) + (npath == 1 ? 11 : 0);
       {   // diagnostic: TNML_EXTRA_LAUNCHES=k adds k trivial dependent launches per step (prices a boundary)
         static const int extra = getenv("TNML_EXTRA_LAUNCHES") ? atoi(getenv("TNML_EXTRA_LAUNCHES")) : 0;
         for (int x = 0; x < extra; ++x) launch_scale(c->scal, 1, 1.0f, c->stream);
@@ -1062,6 +1132,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     HIP_TRY(hipGetLastError());
     c->f_current = true;
   }
+  if (sw_ev1) HIP_TRY(hipEventRecord(sw_ev1, c->stream));
   if (metrics_out) {
     HIP_TRY(hipMemcpyAsync(metrics_out, c->metrics, (size_t)n_steps * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   }
@@ -1347,10 +1418,26 @@ extern "C" int tnml_timer_stop(tnml_ctx *c, double *elapsed_ms) {
 }
 extern "C" int tnml_profile_enable(tnml_ctx *c, int on) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
-  c->profile = on != 0;
+  c->profile = on == 1;            // 1: HIP events around every launch (synchronises after each)
+  c->sweep_timing = on == 2;       // 2: one event pair per tnml_sweep call, nothing waits inside the timed region
   return TNML_OK;
 }
 extern "C" int tnml_profile_get(tnml_ctx *c, int which, double *ms, long long *launches) {
+  if (c && (which == 4 || which == 5)) {
+    // 4: device time between the first and the last launch of every tnml_sweep call since the last reset, and the number
+    //    of kernel launches those calls made; 5: the same time, and the number of single-launch (pipelined) steps
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i + 1 < c->sweep_ev_used; i += 2) {
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, c->sweep_ev[i], c->sweep_ev[i + 1]));
+      c->sweep_ms += t;
+    }
+    c->sweep_ev_used = 0;
+    if (ms) *ms = c->sweep_ms;
+    if (launches) *launches = which == 4 ? c->sweep_launches : c->step_launches;
+    return TNML_OK;
+  }
   if (!c || which < 0 || which > 3) return fail(TNML_ERR_ARG, "bad argument");
   if (ms) *ms = c->prof_ms[which];
   if (launches) *launches = c->prof_n[which];
@@ -1370,5 +1457,6 @@ extern "C" int tnml_svd_stats(tnml_ctx *c, int reset, double *out3) {
 extern "C" int tnml_profile_reset(tnml_ctx *c) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   for (int i = 0; i < 4; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  c->sweep_ms = 0; c->sweep_launches = 0; c->step_launches = 0; c->sweep_ev_used = 0;
   return TNML_OK;
 }

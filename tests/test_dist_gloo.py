@@ -1,7 +1,8 @@
-"""World-size-2 tests of the batch-sharded path on CPU (gloo): the shard helper, the unique-id
-hand-off, and -- with the oracle standing in for the per-rank device work -- that the one message a
-step exchanges (sum of per-shard raw bond gradients + metric slots) reproduces the single-rank step
-exactly, so that replicated update + SVD keeps the ranks identical."""
+"""World-size-2 tests of the batch-sharded path on CPU (gloo): the shard helper, the file-store rendezvous (unique-id
+hand-off, barrier, max over ranks), and -- with the oracle standing in for the per-rank device work -- that the one
+message a step exchanges (sum over the shards of the PRE-gradient Z, the batch sum taken before the behind environment is
+extended with the previous step's new core, + metric slots) reproduces the single-rank step exactly once every rank has
+contracted it with that core (dB = A^T . Z), so that replicated update + SVD keeps the ranks identical."""
 import os
 import socket
 import sys
@@ -30,10 +31,14 @@ def _worker(rank, world, port, out_dir):
     import torch.distributed as dist
     from tensornetworkforml_amd import dist as tdist
     from oracle import mps_oracle as mo
-    tdist.init_process_group(rank, world, 'gloo')
-    # 1. the unique-id hand-off (a fake 128-byte id: RCCL itself needs GPUs)
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)      # the test's own all-reduce below
+    # 1. the library's rendezvous: a file store, no torch (a fake 128-byte id: RCCL itself needs GPUs)
+    grp = tdist.init_process_group(rank, world)
     uid = tdist.broadcast_unique_id(lambda: bytes(range(128)), rank)
     assert uid == bytes(range(128))
+    grp.barrier()
+    assert grp.max_float(1.5 + rank) == 1.5 + world - 1
+    assert grp.broadcast_bytes(b'from-one' if rank == 1 else b'', src=1) == b'from-one'
     # 2. one sweep step, sharded
     rng = np.random.default_rng(0)                     # same stream on every rank
     N, M, D, L, b = 10, 4, 2, 3, 37                    # odd batch: ragged shards
@@ -58,9 +63,21 @@ def _worker(rank, world, port, out_dir):
         fa = rec['fa']
         correct = float((np.argmax(fa, 0) == ys).sum())
         sum_abs = float(np.abs(mo.one_hot(ys, L) - fa).sum())
-        msg = torch.from_numpy(tdist.pack_payload(rec['dB_raw'], correct, sum_abs, 0, len(ys)).astype(np.float64))
+        # pre-gradient of this shard: the batch sum BEFORE the extension with the previous step's new core A_{p-1}
+        #   Z[(a', x), d, e, c, l] = sum_s g[l,s] E_{p-2}[s,a'] x_{p-1}[s,x] x_p[s,d] x_{p+1}[s,e] R[s,c]      (p >= 1)
+        p_ = rec['p']
+        if p_ >= 1:
+            Eprev = mine.Lenv[p_ - 2] if p_ >= 2 else np.ones((len(ys), 1))
+            Z = np.einsum('lb,ba,bx,bd,be,bc->axdecl', rec['g'], Eprev, mine.X[:, p_ - 1], mine.X[:, p_], mine.X[:, p_ + 1], rec['R'])
+        else:
+            Z = rec['dB_raw']
+        msg = torch.from_numpy(tdist.pack_payload(Z, correct, sum_abs, 0, len(ys)).astype(np.float64))
         dist.all_reduce(msg)                                                   # THE exchange of the step
-        dB, acc, mae, bad = tdist.unpack_payload(msg.numpy(), L)
+        Zsum, acc, mae, bad = tdist.unpack_payload(msg.numpy(), L)
+        if p_ >= 1:                                                            # every rank alike: dB = A_{p-1}^T . Z
+            dB = np.einsum('axh,axdecl->hdecl', mine.cores[p_ - 1], Zsum.reshape(Z.shape))
+        else:
+            dB = Zsum.reshape(Z.shape)
         np.testing.assert_allclose(dB.reshape(rec_full['dB_raw'].shape), rec_full['dB_raw'], rtol=1e-5, atol=1e-6 * np.abs(rec_full['dB_raw']).max())
         assert abs(acc - rec_full['accuracy']) < 1e-9 and abs(mae - rec_full['MAE']) < 1e-6 and not bad
         # replicated update from the summed gradient: every rank must land on the full-batch cores
@@ -70,17 +87,14 @@ def _worker(rank, world, port, out_dir):
         np.testing.assert_allclose(f_mine, f_full[:, lo:hi], rtol=1e-4, atol=1e-6)
     dist.barrier()
     open(os.path.join(out_dir, 'ok%d' % rank), 'w').write('ok')
+    grp.destroy_process_group()
     dist.destroy_process_group()
 
 
 def _replicated_step(mo, st, f_prev, ys, dB_raw_global, hp):
     """What every rank does after the all-reduce: the oracle's step with the local gradient replaced
     by the global one (the device's narrow kernel reads the reduced buffer in the same way)."""
-    orig = np.matmul
-
-    class _Patched:
-        pass
-    # run the oracle step but override the gradient: easiest is to re-implement the tail here
+    # the oracle's step with the gradient overridden: its tail is re-implemented here
     N, D, L = st.N, st.D, st.L
     p = st.l_pos
     rec = {}

@@ -180,3 +180,33 @@ def test_adaptive_rank_is_the_index_the_reference_computes():
     assert mo.adaptive_rank(S, 2, 0.85) == 2                     # capped by M
     assert mo.adaptive_rank(S, 6, 0.999999) == 1 + int(np.argmax(cum > 0.999999))
     assert mo.trunc_rank('adaptive', False, 3, 10, 4, 2, 4, 2, 5) == (5, True)
+
+
+@pytest.mark.parametrize('name', ['traj_fixed_softmax_full_cross_ent_L21', 'traj_reference_softmax_full_cross_ent_L21',
+                                  'traj_fixed_L3', 'traj_fixed_sigmoid_MSE_L20', 'traj_reference_N16_script',
+                                  'traj_fixed_softmax_full_cross_ent_L20'])
+def test_reference_form_matches_goldens(name):
+    """oracle/mps_reference_form.py (the reference's own computational form: broadcast-multiply-sum contractions, L2 norm
+    environments rebuilt at every step; bench.py's cpu_baseline_reference_form) reproduces the reference's f of every
+    step, free-running from the initial cores."""
+    from oracle import mps_reference_form as rf
+    d = gu.load(name)
+    N, M, L, D = int(d['N']), int(d['M']), int(d['L']), int(d['D'])
+    kw = _step_kwargs(d)
+    y1h = mo.one_hot(d['y'], L)
+    st = mo.MPSState(N, D, L, M, gu.indexed(d, 'init_core', N), 0)
+    k = 0
+    for sw in range(int(d['n_sweeps'])):
+        f = rf.forward(st, d['X'])
+        close(f, d['sw%d_f_forward' % sw], rtol=1e-9)
+        left_dir = bool(d['sw%d_left_dir' % sw])
+        if left_dir:
+            st.Renv = {}
+        else:
+            st.Lenv = {}
+        for j in range(N - 1):
+            f = rf.sweep_step(st, f, y1h, left_dir=left_dir, **kw)
+            close(f, d['st%d_f_new' % k], rtol=1e-8)
+            assert list(st.bond) == [int(x) for x in d['st%d_bond' % k]]
+            k += 1
+    close(rf.forward(st, d['X']), d['final_f'], rtol=1e-8)
