@@ -7,6 +7,12 @@ namespace tnml {
 
 constexpr int kJacobiMaxSweeps = 30;
 
+// Workgroup barrier for hand-offs through LDS only.  __syncthreads() is a workgroup-scope fence plus s_barrier, and the fence
+// drains the wave's GLOBAL stores too (s_waitcnt vmcnt(0)): behind a phase that stored its results to HBM every such barrier
+// costs a memory round trip (2-5 k cycles measured per phase of the step kernel).  Here only LDS traffic is waited for;
+// global hand-offs to other workgroups keep their own explicit s_waitcnt vmcnt(0) + flag protocol.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Rotation (c, s) that annihilates g in [[a, g], [g, b]] under J = [[c, s], [-s, c]] (columns:
 // a' = c a - s b, b' = s a + c b).  level: 0 negligible (identity), 1 small, 2 large -- the sweep
 // loop stops once a whole sweep made only small rotations (quadratic convergence then leaves
@@ -48,6 +54,30 @@ __device__ inline Rot jacobi_rot(double a, double b, double g, double kept2, dou
   if (act) { r.c = c0; r.s = c0 * td; r.t = td; r.level = (g2 > big2 * sc) ? 2 : 1; }
   return r;
 }
+
+// The same rotation from float32 arithmetic only, for the look-ahead chain of the in-LDS kernel (kernels_narrow.hip phase 7).
+// A dependent float64 instruction costs 40 cycles on gfx950 and a float32 one 8-14 (tools/ubench/prims.hip), and this chain
+// sets the length of a Jacobi round.  Returned: t = tan(angle) and c0 ~ 1 / sqrt(1 + t^2), both float32-exact numbers; the
+// threads that APPLY the rotation refine c to float64 themselves,
+//     c = c0 (1.5 - 0.5 (1 + t^2) c0^2),   s = c t            (one Newton step: c^2 + s^2 = 1 to ~1e-14),
+// so every rotation is orthogonal to float64 accuracy whatever the accuracy of t -- the angle only decides how well the
+// off-diagonal element is annihilated (relative error ~1e-7: the next sweep sees an element 1e-7 of the old one), and the
+// thresholds below are compared at float32 accuracy, which their margins (factors of 1e6 and more) absorb.
+struct RotT { float t, c0; int level; };
+__device__ inline RotT jacobi_rot_f32(float a, float b, float g, float kept2, float abs2, float big2) {
+  RotT r; r.t = 0.f; r.c0 = 1.f; r.level = 0;
+  const float g2 = g * g;
+  const float sc = fmaxf(fabsf(a * b), kept2);
+  const bool act = g2 > fmaxf((float)kJacobiTol2 * sc, abs2);   // false for g == 0 and NaN
+  const float df = b - a;
+  const float hyp = __builtin_amdgcn_sqrtf(fmaf(df, df, 4.f * g2));
+  const float t = 2.f * g * __builtin_amdgcn_rcpf(df + copysignf(hyp, df));
+  const float c0 = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
+  if (act) { r.t = t; r.c0 = c0; r.level = (g2 > big2 * sc) ? 2 : 1; }
+  return r;
+}
+// float64 cosine of the rotation (t, c0) published by jacobi_rot_f32: c0 * corr, corr = 1.5 - 0.5 (1 + t^2) c0^2
+__device__ inline double rot_corr(double t, double c0) { return fma(-0.5 * fma(t, t, 1.0), c0 * c0, 1.5); }
 
 // one-lane wave shift of a double: CTRL 0x138 = wave_shr:1 (lane i receives lane i-1), 0x130 = wave_shl:1
 template <int CTRL> __device__ inline double dpp_f64(double v) {

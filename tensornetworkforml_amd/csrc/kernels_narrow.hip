@@ -29,45 +29,54 @@
 
 namespace tnml {
 
-// block-wide sum of up to 3 doubles; result valid in every thread.  scratch: >= 3*16 doubles.
+// sum of a double over the 64 lanes of a wave, identical in every lane, without the LDS crossbar: xor-butterfly inside
+// every 16-lane row by DPP (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: fp addition is
+// commutative, so all lanes of a row end with the same bits), then the four row totals by v_readlane
+__device__ inline double wave_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  const double r0 = wave_read_f64(v, 0), r1 = wave_read_f64(v, 16), r2 = wave_read_f64(v, 32), r3 = wave_read_f64(v, 48);
+  return (r0 + r1) + (r2 + r3);
+}
+
+// block-wide sum of up to 3 doubles; result valid (and bitwise identical) in every thread.  scratch: >= 3*16 doubles.
 __device__ inline void block_sum3(double &a, double &b, double &c, double *scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_xor(a, off);
-    b += __shfl_xor(b, off);
-    c += __shfl_xor(c, off);
-  }
-  __syncthreads();
+  a = wave_sum_f64(a); b = wave_sum_f64(b); c = wave_sum_f64(c);
+  lds_barrier();
   if (lane == 0) { scratch[wave] = a; scratch[16 + wave] = b; scratch[32 + wave] = c; }
-  __syncthreads();
-  // every wave combines the (<= 16) wave partials with the same shuffle tree: identical result in all threads
-  a = lane < nw ? scratch[lane] : 0.0;
-  b = lane < nw ? scratch[16 + lane] : 0.0;
-  c = lane < nw ? scratch[32 + lane] : 0.0;
-  for (int off = 8; off > 0; off >>= 1) {
-    a += __shfl_xor(a, off);
-    b += __shfl_xor(b, off);
-    c += __shfl_xor(c, off);
-  }
-  a = __shfl(a, 0); b = __shfl(b, 0); c = __shfl(c, 0);
-  __syncthreads();
+  lds_barrier();
+  double ta = 0.0, tb = 0.0, tc = 0.0;
+  for (int w = 0; w < nw; ++w) { ta += scratch[w]; tb += scratch[16 + w]; tc += scratch[32 + w]; }   // wave order, broadcast reads
+  a = ta; b = tb; c = tc;
+  lds_barrier();
 }
 
 struct NarrowCarve {
-  double *dT, *dG, *Z, *dNh, *dNg, *dLam, *dRed, *dT2, *dCS, *dSq;
-  float *fB, *fBp, *sLab, *sPl, *sCb;
-  int *sOrd, *sFlag, *sPi, *sPiInv;
+  double *dT, *dG, *Z, *dNh, *dNg, *dLam, *dRed, *dT2, *dCS, *dSq, *dVs;
+  float *fB, *fBp, *sLab, *sPl, *sCb, *sLab2, *sPl2;
+  double *dNg2;
+  int *sOrd, *sFlag, *sPi, *sPiInv, *sWave;
   float *sTail;
   size_t bytes;
 };
 
-__host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, int g, int s, int L, int m) {
+// doubles of the tail preparation (phase 12) inside the Jacobi region: T (double), Nh_new (double), B' (float)
+__host__ __device__ inline size_t narrow_tail_doubles(int g, int L, int m, int g2) {
+  const size_t Bs2 = (size_t)m * kD * kD * g2 * L;
+  return Bs2 + (((size_t)m * m + 1) & ~(size_t)1) + (Bs2 + 5) / 2 + 2;
+}
+
+__host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, int g, int s, int L, int m, int g2 = 0) {
   const int D = kD;
   const size_t Bs = (size_t)h * D * D * g * L;
   const int r = D * h, c = D * g * L;
   const int n = r <= c ? r : c, ne = n + (n & 1);
   size_t zreg = 2 * Bs;
   if ((size_t)4 * ne * ne > zreg) zreg = (size_t)4 * ne * ne;   // G and V, two buffers each, ne x ne
+  if (g2 > 0 && narrow_tail_doubles(g, L, m, g2) > zreg) zreg = narrow_tail_doubles(g, L, m, g2);
   NarrowCarve k;
   double *d = (double *)base;
   k.dT = d; k.dG = d + Bs; k.Z = d; d += zreg;
@@ -78,24 +87,29 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
   k.dT2 = d; d += (size_t)h * D * m;
   k.dCS = d; d += 4 * ne;                   // (c, s, t, -) per pair, two rounds in flight
   k.dSq = d; d += 2 * ne;                   // sigma^(1/2) and sigma^(-1/2) of the kept columns
+  k.dVs = d; d += (size_t)ne * m;           // kept eigenvectors, columns in descending order of the eigenvalue
+  k.dNg2 = d; d += ((size_t)g2 * g2 + 1) & ~(size_t)1;     // ahead norm environment of the NEXT step (tail preparation)
   float *f = (float *)d;
   k.fB = f; f += Bs;
   k.fBp = f; f += Bs + (size_t)(D * h < D * g * L ? D * h : D * g * L) + 4;   // rows at stride (cols + 1): bank-conflict-free
   k.sLab = f; f += (size_t)h * D * s * L;
   k.sPl = f; f += (size_t)s * D * g;
   k.sCb = f; f += (size_t)r * m;
+  k.sLab2 = f; f += (size_t)m * c;          // the new label core [s'][(dk1, g_, l)] (float-rounded, as stored)
+  k.sPl2 = f; f += ((size_t)g * kD * g2 + 3) & ~(size_t)3;   // plain core of the next step's ahead site (tail preparation)
   int *ip = (int *)f;
   k.sOrd = ip; ip += ne;
   k.sFlag = ip; ip += 8;
   k.sPi = ip; ip += ne;
   k.sPiInv = ip; ip += ne;
   k.sTail = (float *)ip; ip += kMetricSlots;
+  k.sWave = ip; ip += 16;
   k.bytes = (size_t)((unsigned char *)ip - base);
   return k;
 }
 
-size_t narrow_lds_bytes(int h, int g, int s, int L, int m) {
-  return narrow_carve(nullptr, h, g, s, L, m).bytes + 16;
+size_t narrow_lds_bytes(int h, int g, int s, int L, int m, int g2) {
+  return narrow_carve(nullptr, h, g, s, L, m, g2).bytes + 16;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -132,18 +146,18 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
       float t = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) t += part[c * 64 + el];
-      p.red_out[e] = t;
+      __hip_atomic_store(p.red_out + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
     PrepParams q{};
     q.lab = p.lab; q.pl = p.pl; q.Nh = p.Nh; q.Ng = p.Ng; q.h = h; q.g = g; q.s = s; q.L = L; q.l2_flag = p.l2_flag;
     q.prepB = p.prepB; q.prepG = p.prepG;
-    prep_slice_block(q, blk - p.nred, smem_raw);
+    prep_slice_block(q, blk - p.nred, smem_raw, true);
   }
-  // hand-off to workgroup 0 (other CU, possibly other XCD: L1 and L2 are not coherent across them): every storing
-  // wave drains its stores, the workgroup meets, then ONE agent-scope release (L2 write-back) bumps the counter;
-  // workgroup 0 acquires it and reads the data with agent-scope (sc1) loads (MI355X_MICROARCH.md, correctness
-  // boundaries)
+  // hand-off to workgroup 0 (other CU, possibly other XCD: L1 and L2 are not coherent across them), first row of the
+  // hand-off table of MI355X_MICROARCH.md: every handed-off byte was stored with an agent-scope (sc1, write-through)
+  // store, every storing wave drains its stores, the workgroup meets, ONE lane bumps the counter (relaxed: no L2
+  // write-back to wait for); workgroup 0 polls it relaxed and reads the data with agent-scope (sc1) loads
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
@@ -151,12 +165,12 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
       atomicMin(p.counters + (blk < p.nred ? 4 : 5), t_start);
       atomicMax(p.counters + (blk < p.nred ? 6 : 7), __builtin_amdgcn_s_memrealtime());
     }
-    __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char *smem_raw) {
-  const NarrowCarve k = narrow_carve(smem_raw, p.h, p.g, p.s, p.L, p.m);
+  const NarrowCarve k = narrow_carve(smem_raw, p.h, p.g, p.s, p.L, p.m, p.tail_prep ? p.g2 : 0);
   const int tid = threadIdx.x, NT = kNarrowThreads;
   const int D = kD, h = p.h, g = p.g, s = p.s, L = p.L, m = p.m, Bs = p.bsize;
   // reduced gradient + metric tail: written by other workgroups of THIS launch when fused -> coherent loads
@@ -176,25 +190,121 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   unsigned long long t_p[5] = {0, 0, 0, 0, 0};
 #ifdef TNML_EXP_FINE_STAMPS
   unsigned long long t_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_y[24];
+  for (int i = 0; i < 24; ++i) t_y[i] = 0;
 #define XSTAMP(i) if (p.stamps && tid == 0) t_x[i] = __builtin_amdgcn_s_memtime()
+#define YSTAMP(i) if (p.stamps && tid == 0) t_y[i] = __builtin_amdgcn_s_memtime()
 #else
 #define XSTAMP(i)
+#define YSTAMP(i)
 #endif
 #define TNML_STAMP(i) if (p.stamps && tid == 0) t_p[i] = __builtin_amdgcn_s_memtime()
   if (p.stamps && tid == 0) { t_c0 = __builtin_amdgcn_s_memtime(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
   // ---- pipelined step: raw gradient dB[h_, rest] = sum_i' A_{k-1}[i', h_] Z_k[i', rest] (wide_pipe_device.h); both operands
   // were completed by the previous launch, so this runs before anything of this launch is waited for
   const int RWz = kD * kD * p.g * p.L;
-  if (p.pipe && !p.z_first) {
+  // Pipelined launch whose merged tensor / L2 term were prepared by the previous launch's tail: EVERY global operand of
+  // this workgroup is requested at once (16-byte loads where the layout allows) and lands in LDS after one round trip --
+  // a loop of dependent load -> LDS-store iterations costs one round trip per iteration (7 for the reduced pre-gradient).
+  const bool fast0 = p.pipe && (size_t)p.z_rows * RWz + (size_t)p.z_rows * h <= (size_t)((float *)k.sOrd - k.fBp) &&
+                     Bs <= 8 * NT && p.z_rows * RWz <= 16 * NT && p.z_rows * h <= 4 * NT && h * h <= 2 * NT && g * g <= 2 * NT &&
+                     g * D * p.g2 <= 2 * NT && p.g2 * p.g2 <= 2 * NT;
+  float *sZ = k.fBp, *sZc = sZ + (size_t)p.z_rows * RWz;
+  if (fast0) {
+    const int zr = p.z_rows, nz = p.z_first ? 0 : zr * RWz, nzc = p.z_first ? 0 : zr * h;
+    const float *zc = p.zcore.base;
+    float4 rz[4], rb[2];
+    double2 rg[4];
+    float rc[4], rpl[2];
+    double rnh[2], rng[2], rng2[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = 4 * (tid + u * NT); rz[u] = e < nz ? *reinterpret_cast<const float4 *>(p.zred + e) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int e = 4 * (tid + u * NT); rb[u] = (p.prep_ready && e < Bs) ? *reinterpret_cast<const float4 *>(p.prepB + e) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = 2 * (tid + u * NT); rg[u] = (p.prep_ready && p.l2_flag && e < Bs) ? *reinterpret_cast<const double2 *>(p.prepG + e) : make_double2(0.0, 0.0); }
+    const float inv_h = 1.0f / (float)h, inv_g2 = p.g2 > 0 ? 1.0f / (float)p.g2 : 0.f;   // exact quotients for these small integers
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + u * NT, i2 = (int)(((float)e + 0.5f) * inv_h), hh = e - i2 * h;
+      rc[u] = e < nzc ? zc[(i2 >> 1) * p.zcore.s_in + (i2 & 1) * p.zcore.s_d + hh * p.zcore.s_out] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * NT;
+      rnh[u] = (p.Nh && e < h * h) ? p.Nh[e] : 1.0;
+      rng[u] = (p.Ng && e < g * g) ? p.Ng[e] : 1.0;
+      rng2[u] = (p.tail_prep && p.Ng2 && e < p.g2 * p.g2) ? p.Ng2[e] : 1.0;
+      const int q2 = (int)(((float)e + 0.5f) * inv_g2), g_ = e - q2 * p.g2;
+      rpl[u] = (p.tail_prep && e < g * D * p.g2) ? p.pl2.base[(q2 / D) * p.pl2.s_in + (q2 % D) * p.pl2.s_d + g_ * p.pl2.s_out] : 0.f;
+    }
+    YSTAMP(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = 4 * (tid + u * NT); if (e < nz) *reinterpret_cast<float4 *>(sZ + e) = rz[u]; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int e = 4 * (tid + u * NT); if (p.prep_ready && e < Bs) *reinterpret_cast<float4 *>(k.fB + e) = rb[u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = 2 * (tid + u * NT); if (p.prep_ready && p.l2_flag && e < Bs) *reinterpret_cast<double2 *>(k.dG + e) = rg[u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = tid + u * NT; if (e < nzc) sZc[e] = rc[u]; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * NT;
+      if (e < h * h) k.dNh[e] = rnh[u];
+      if (e < g * g) k.dNg[e] = rng[u];
+      if (p.tail_prep && e < p.g2 * p.g2) k.dNg2[e] = rng2[u];
+      if (p.tail_prep && e < g * D * p.g2) k.sPl2[e] = rpl[u];
+    }
+    YSTAMP(1);
+    lds_barrier();
+    YSTAMP(2);
+    if (!p.z_first)
+      mm_lds_f32(h, RWz, zr, sZc, 1, h, sZ, RWz, 1, [&](int i, int j, float v) { k.dT[i * RWz + j] = (double)v; });
+    YSTAMP(3);
+    if (!p.prep_ready) {
+      // merged tensor and L2 term from the slice workgroups of THIS launch: wait for their arrivals, then agent-scope loads,
+      // all in flight together
+      if (tid == 0) {
+        const unsigned want = (unsigned)p.wait_count;
+        int spins = 0;
+        // relaxed agent-scope poll: every load of the handed-off bytes below is an agent-scope (sc1) load, so no acquire --
+        // an acquire invalidates this CU's L1 and costs ~1.7 us per poll (MI355X_MICROARCH.md, hand-off table, first row)
+        while (__hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1 << 22)) {
+          __builtin_amdgcn_s_sleep(2);
+          ++spins;
+        }
+        if (spins >= (1 << 22)) atomicOr(p.status, 4);
+        __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      lds_barrier();
+      float qb[8];
+      double qg[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = tid + u * NT;
+        qb[u] = e < Bs ? ld_sc1(p.prepB + e) : 0.f;
+        qg[u] = (p.l2_flag && e < Bs) ? __hip_atomic_load(p.prepG + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = tid + u * NT;
+        if (e < Bs) { k.fB[e] = qb[u]; if (p.l2_flag) k.dG[e] = qg[u]; }
+      }
+    }
+    YSTAMP(4);
+  } else if (p.pipe && !p.z_first) {
     const float *zc = p.zcore.base;
     const int zs_in = p.zcore.s_in, zs_d = p.zcore.s_d, zs_out = p.zcore.s_out;
-    small_gemm_f64(1, h, RWz, p.z_rows,
+    const int zr = p.z_rows;
+    small_gemm_f64(1, h, RWz, zr,
                    [&](int, int i, int kk) { return (double)zc[(kk >> 1) * zs_in + (kk & 1) * zs_d + i * zs_out]; },
                    [&](int, int kk, int j) { return (double)p.zred[(size_t)kk * RWz + j]; },
                    [&](int, int i, int j, double v) { k.dT[i * RWz + j] = v; });
   }
   // ---- phase 0: stage the two cores and the norm environments ---------------------------------
-  if (p.fused) {
+  if (fast0) {
+    // everything is in LDS already
+  } else if (p.fused) {
     // B and Ln.B.Rn come from the slice workgroups of the preceding wide launch (prep_ready: plain loads, issued
     // before the wait) or of this launch; red always from the reduce workgroups of this launch
     if (p.prep_ready)
@@ -222,7 +332,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
         p.counters[4] = ~0ull; p.counters[5] = ~0ull; p.counters[6] = 0ull; p.counters[7] = 0ull;
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (!p.prep_ready) for (int e = tid; e < Bs; e += NT) {
       k.fB[e] = __hip_atomic_load(p.prepB + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (p.l2_flag) k.dG[e] = __hip_atomic_load(p.prepG + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -248,9 +358,18 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   } else {
     for (int e = tid; e < Bs; e += NT) k.fB[e] = p.Bdirect[e];
   }
-  for (int e = tid; e < h * h; e += NT) k.dNh[e] = p.Nh ? p.Nh[e] : 1.0;
-  for (int e = tid; e < g * g; e += NT) k.dNg[e] = p.Ng ? p.Ng[e] : 1.0;
-  __syncthreads();
+  if (!fast0) {
+    for (int e = tid; e < h * h; e += NT) k.dNh[e] = p.Nh ? p.Nh[e] : 1.0;
+    for (int e = tid; e < g * g; e += NT) k.dNg[e] = p.Ng ? p.Ng[e] : 1.0;
+    if (p.tail_prep) {             // operands of the next step that exist already: its plain core and its ahead norm environment
+      for (int e = tid; e < g * D * p.g2; e += NT) {
+        const int g_ = e % p.g2, q2 = e / p.g2;
+        k.sPl2[e] = p.pl2.base[(q2 / D) * p.pl2.s_in + (q2 % D) * p.pl2.s_d + g_ * p.pl2.s_out];
+      }
+      for (int e = tid; e < p.g2 * p.g2; e += NT) k.dNg2[e] = p.Ng2 ? p.Ng2[e] : 1.0;
+    }
+  }
+  lds_barrier();
 
   TNML_STAMP(0);
   // ---- phase 1: B[h,dk,dk1,g,l] = sum_s lab(h,dk,s,l) * pl(s,dk1,g) ---------------------------
@@ -262,7 +381,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
                    [&](int l, int kk, int j) { return (double)k.sPl[kk * QW + j]; },
                    [&](int l, int i, int j, double v) { k.fB[(i * QW + j) * L + l] = (float)v; });
   }
-  __syncthreads();
+  lds_barrier();
 
   TNML_STAMP(1);
   // ---- phases 2-3: weight decay term ------------------------------------------------------------
@@ -272,13 +391,13 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
                    [&](int, int i, int kk) { return k.dNh[kk * h + i]; },
                    [&](int, int kk, int j) { return (double)k.fB[kk * RW + j]; },
                    [&](int, int i, int j, double v) { k.dT[i * RW + j] = v; });
-    __syncthreads();
+    lds_barrier();
     // G = T . Ng over the ahead bond: rows i = (e_, dk, dk1, l), columns f_
     small_gemm_f64(L, Bs / (g * L), g, g,
                    [&](int l, int i, int kk) { return k.dT[(i * g + kk) * L + l]; },
                    [&](int l, int kk, int j) { return k.dNg[kk * g + j]; },
                    [&](int l, int i, int j, double v) { k.dG[(i * g + j) * L + l] = v; });
-    __syncthreads();
+    lds_barrier();
   }
   TNML_STAMP(2);
   double sumB = 0.0, sumD = 0.0, l2 = 0.0;
@@ -341,7 +460,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     }
   }
   XSTAMP(2);
-  __syncthreads();   // dT/dG are dead from here on; Z aliases them
+  lds_barrier();   // dT/dG are dead from here on; Z aliases them
   // B_new is complete in memory: the batch-side workgroups of this launch may form f and the next pre-gradient from it
   // while this workgroup goes on to the SVD
   if (p.flag && tid == 0) __hip_atomic_store(p.flag, p.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -365,15 +484,19 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // the Jacobi region and are summed in slice order (deterministic).
   constexpr int kGramSplit = 4;
   {
-    double *Pb[kGramSplit] = {G0, G1, V0, k.Z + 3 * ne * ne};
+    double *P0 = G0, *P1 = G1, *P2 = V0, *P3 = k.Z + 3 * ne * ne;
     const int lane = tid & 63, wave = tid >> 6, rr = lane & 15, qq = lane >> 4;
-    const int tm = (n + 15) >> 4, ntile = tm * (tm + 1) / 2;
+    const int tm = (n + 15) >> 4;
     const int kchunk = ((len + kGramSplit - 1) / kGramSplit + 3) & ~3;       // multiple of the MFMA k = 4
-    for (int item = wave; item < ntile * kGramSplit; item += NT >> 6) {
-      const int ks = item % kGramSplit;
-      int t = item / kGramSplit, ti = 0;
-      while (t >= tm - ti) { t -= tm - ti; ++ti; }
-      const int tj = ti + t;
+    // (tile, slice) items dealt round-robin to the waves: nested counters, no integer division (a per-lane division costs
+    // 134 cycles, a wave-uniform one ~40 scalar instructions: tools/ubench/prims.hip)
+    int slot = 0;
+    for (int ti = 0; ti < tm; ++ti)
+     for (int tj = ti; tj < tm; ++tj)
+      for (int ks = 0; ks < kGramSplit; ++ks) {
+      const bool mine = slot == wave;
+      slot = slot + 1 == (NT >> 6) ? 0 : slot + 1;
+      if (!mine) continue;
       const int i0 = ti << 4, j0 = tj << 4;
       const int ia = min(i0 + rr, n - 1), jb = min(j0 + rr, n - 1);
       const bool va = i0 + rr < n, vb = j0 + rr < n;
@@ -397,28 +520,27 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       }
       const dvec4 acc = acc0 + acc1;
       const int j = j0 + rr;
+      double *Pk = ks == 0 ? P0 : (ks == 1 ? P1 : (ks == 2 ? P2 : P3));
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int i = i0 + qq + 4 * reg;
-        if (i < ne && j < ne) Pb[ks][i * ne + j] = (i < n && j < n) ? acc[reg] : 0.0;     // padding row / column = 0
+        if (i < ne && j < ne) Pk[i * ne + j] = (i < n && j < n) ? acc[reg] : 0.0;     // padding row / column = 0
       }
     }
-    __syncthreads();
+    lds_barrier();
     XSTAMP(3);
-    // sum of the slices, in slice order, mirrored into the lower triangle (exact symmetry); tiles below the
-    // diagonal were never written
-    for (int e = tid; e < ne * ne; e += NT) {
-      const int i = e / ne, j = e - i * ne;
-      if ((i >> 4) <= (j >> 4)) {
-        const double v = ((Pb[0][e] + Pb[1][e]) + Pb[2][e]) + Pb[3][e];
-        if (i <= j) G0[e] = v;
-      }
-    }
-    __syncthreads();
-    for (int e = tid; e < ne * ne; e += NT) {
-      const int i = e / ne, j = e - i * ne;
-      if (i > j) G0[e] = G0[j * ne + i];
-    }
+    // sum of the slices, in slice order, mirrored into the lower triangle (exact symmetry); tiles below the diagonal were
+    // never written.  Rows over waves, columns over lanes: no division.
+    for (int i = tid >> 6; i < ne; i += NT >> 6)
+      for (int j = tid & 63; j < ne; j += 64)
+        if ((i >> 4) <= (j >> 4)) {
+          const int e = i * ne + j;
+          const double v = ((P0[e] + P1[e]) + P2[e]) + P3[e];
+          if (i <= j) P0[e] = v;                                  // P0 == G0: in place
+        }
+    lds_barrier();
+    for (int i = tid >> 6; i < ne; i += NT >> 6)
+      for (int j = tid & 63; j < i && j < ne; j += 64) G0[i * ne + j] = G0[j * ne + i];
   }
   XSTAMP(4);
   // Tournament in POSITION space: the pairs of a round are always the positions (2k, 2k+1); after
@@ -434,7 +556,12 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     k.sPi[pos] = nxt;
     k.sPiInv[nxt] = pos;
   }
-  __syncthreads();
+  // SIMD of every wave (HW_REG_HW_ID bits 5:4): the Jacobi iteration keeps the SIMD of the parameter wave (wave 0) free of
+  // working waves -- its dependent chain of ~30 instructions sets the length of a round, and co-resident waves that issue
+  // float64 instructions of their own delay every link of it (round-1 timing experiment: parameters alone 740 cycles per
+  // round, next to the other roles 1130)
+  if ((tid & 63) == 0) k.sWave[tid >> 6] = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+  lds_barrier();
   TNML_STAMP(4);
   // scale G to trace ~ 1 by an exact power of two (undone on the eigenvalues in phase 8)
   double tr = 0.0;                                        // n <= 64: one diagonal entry per lane, same tree in every wave
@@ -444,7 +571,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     for (int off = 32; off > 0; off >>= 1) tr += __shfl_xor(tr, off);
   }
   const int sc_exp = (tr > 0.0 && isfinite(tr)) ? __builtin_amdgcn_frexp_exp(tr) : 0;
-  __syncthreads();
+  lds_barrier();
   double off2 = 0.0, dg2 = 0.0, dummy = 0.0;
   const bool chol_possible = p.chol_thr > 0.0 && n > 4;   // tiny matrices (chain ends, reference policy): not worth a reduction
   for (int e = tid; e < ne * ne; e += NT) {
@@ -453,7 +580,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     if (e / ne == e % ne) dg2 += v * v; else off2 += v * v;
   }
   if (chol_possible) block_sum3(off2, dg2, dummy, k.dRed);
-  else __syncthreads();
+  else lds_barrier();
 
   // ---- phase 6b: one pivoted-Cholesky step when G is far from diagonal ------------------------------------------
   // G = L L^T (diagonal pivoting), G' = L^T L has the same eigenvalues and is graded: the Jacobi iteration then needs
@@ -503,7 +630,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     };
     if (tid < 64) pivot_search(0);
     for (int kc = 0; kc < n; ++kc) {
-      __syncthreads();                                     // A: pivot known; the previous update is complete
+      lds_barrier();                                     // A: pivot known; the previous update is complete
       const int jp = k.sFlag[4 + (kc & 1)];
       if (jp < 0) break;                                   // numerically rank deficient: the remaining columns stay zero
       const double inv = k.dRed[61 + (kc & 1)];
@@ -521,7 +648,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
         if (tid < n) Lm[kc * ne + tid] = l;                // L stored transposed: row kc = column kc of L
         dgi = (tid == jp) ? -1.0 : (dgi >= 0.0 ? dgi - l * l : dgi);
       }
-      __syncthreads();                                     // B: everybody holds its column values
+      lds_barrier();                                     // B: everybody holds its column values
       if (tid < 64) {
         if (kc + 1 < n) pivot_search((kc + 1) & 1);
       } else {
@@ -536,19 +663,19 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
           }
       }
     }
-    __syncthreads();
+    lds_barrier();
     XSTAMP(6);
     // G' = L^T L into G0 (the trailing matrix is dead)
     small_gemm_f64(1, n, n, n,
                    [&](int, int a, int i) { return Lm[a * ne + i]; },
                    [&](int, int i, int b) { return Lm[b * ne + i]; },
                    [&](int, int a, int b, double v) { G0[a * ne + b] = v; });
-    __syncthreads();
+    lds_barrier();
     for (int e = tid; e < n * n; e += NT) {                // exact symmetry
       const int i = e / n, j = e - i * n;
       if (i > j) G0[i * ne + j] = G0[j * ne + i];
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   XSTAMP(7);
@@ -564,14 +691,31 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   //   column pair Q = its lane within a group of np lanes) in registers; the column rotation is local and
   //   the tournament move (top element of pair Q -> pair Q+1, bottom element -> pair Q-1) is a one-lane
   //   wave shift (DPP wave_shr / wave_shl, tools/ubench/dpp_wave_shift.hip).
-  constexpr int kVR = 2;
+  constexpr int kVR = 2;                                 // register blocks per V lane (upper bound); vr of them are used:
   const int gpw = 64 / np;                               // groups of np lanes per V wave (np <= 32)
-  const int NVW = (np + kVR * gpw - 1) / (kVR * gpw);    // V waves
-  const int T0 = 64 * (1 + NVW);
-  const int NW = NT - T0;
+  // one block per lane when the V and G waves then still fit the workgroup (n <= 40: 7 + 4 of 15), two otherwise
+  const int vr = ((np + gpw - 1) / gpw + (np * (np + 1) / 2 + 127) / 128 <= (NT >> 6) - 1) ? 1 : 2;
+  const int NVW = (np + vr * gpw - 1) / (vr * gpw);      // V waves
+  // worker waves = the waves that do not share wave 0's SIMD, numbered densely (wrank); if the placement leaves too few
+  // of them (never observed: 16 waves spread 4 per SIMD), every wave but wave 0 works as before
+  int wrank = -1, nwork = 0;
+  {
+    const int mywave = tid >> 6, simd0 = k.sWave[0];
+    for (int w = 1; w < (NT >> 6); ++w) {
+      const bool shares = k.sWave[w] == simd0;
+      if (w == mywave && !shares) wrank = nwork;
+      nwork += shares ? 0 : 1;
+    }
+    const int nGw = (np * (np + 1) / 2 + 127) / 128;       // G waves needed at two items per thread
+    // (measured, round 2: once the parameter chain runs in float32 the round is bound by the float64 issue rate of the
+    // working waves, and giving them all four SIMDs is worth more than keeping the parameter wave's SIMD free)
+    if (true || nwork < NVW + nGw) { nwork = (NT >> 6) - 1; wrank = mywave - 1; }
+  }
+  const int NW = (nwork - NVW) * 64;                     // threads that own G items
+  const int gtid = (wrank - NVW) * 64 + (tid & 63);      // index among them (negative: not a G wave)
   const int vlane = tid & 63, vgrp = vlane / np, vQ = vlane - vgrp * np;
-  const bool isVwave = tid >= 64 && tid < T0;
-  const int vP0 = (((tid >> 6) - 1) * gpw + vgrp) * kVR;
+  const bool isVwave = wrank >= 0 && wrank < NVW;
+  const int vP0 = (wrank * gpw + vgrp) * vr;
   const bool vLaneOk = isVwave && vgrp < gpw;
   double vb[kVR][4];                                     // {v11, v12, v21, v22} per block
 #pragma unroll
@@ -589,8 +733,8 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   int itSrc[MAXI], itCsQ[MAXI], itCsP[MAXI], itD11[MAXI], itD12[MAXI], itD21[MAXI], itD22[MAXI];
 #pragma unroll
   for (int u = 0; u < MAXI; ++u) {
-    const int it = (tid - T0) + u * NW;
-    itValid[u] = tid >= T0 && it < nG;
+    const int it = gtid + u * NW;
+    itValid[u] = wrank >= NVW && it < nG;
     int P = 0, Q = 0;
     if (itValid[u]) {                         // it-th pair (P <= Q) in row-major order of the upper triangle
       int rem = it;
@@ -622,7 +766,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       const int rank = __popcll(__ballot(i < n && ((li > lj) || (li == lj && i < j))));
       if (i == 0 && rank == m - 1) k.dRed[60] = lj;
     }
-    __syncthreads();
+    lds_barrier();
     const double lm = kKeptFrac * fmax(k.dRed[60], 0.0);
     return lm * lm;
   };
@@ -631,14 +775,29 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   double kept2 = 0.0;
   // one round; xP / xG / xV switch the parameter threads, the G items and the V items (all true except in
   // the timing experiment at the end of the kernel)
-  auto jacobi_round = [&](const bool stampRound, const bool xP, const bool xG, const bool xV) {
+  // Rotation slot of pair k in dCS (4 doubles): [0] t, [1] c0 as doubles (float32-exact values), [2] the same two as a
+  // float2 for the look-ahead chain.  See jacobi_rot_f32 (jacobi_device.h) for the arithmetic.
+  const float kept_lo = 1e-36f;
+  // `applied` = index of the round in which the rotation will be applied.  A "big" rotation (jacobi_device.h) leaves its
+  // round index + 1 in slot applied & 1 of sFlag[6..7]: every thread reads that slot at the top of round `applied` (the
+  // barrier of the previous round completed the writes; the slot is next written two rounds later), so all threads know
+  // the last round that applied a big rotation without any reduction.
+  auto publish = [&](double *o, const RotT &r, int applied) {
+    *reinterpret_cast<double2 *>(o) = make_double2((double)r.t, (double)r.c0);
+    *reinterpret_cast<float2 *>(o + 2) = make_float2(r.t, r.c0);
+    if (r.level >= 2) k.sFlag[6 + (applied & 1)] = applied + 1;
+  };
+  int round_idx = 0, last_big1 = 0;          // rounds applied so far; 1 + index of the last round with a big rotation
+  auto jacobi_round = [&](const bool stampRound, const bool xP, const bool xG, const bool xV, const bool stampAll = false) {
         const double *csc = k.dCS + cur * np * 4;
+        const int big_slot = k.sFlag[6 + (round_idx & 1)];      // consumed after this round's barrier
         unsigned long long r_t0 = 0, r_t1 = 0, r_t2 = 0, r_t3 = 0;
         if (stampRound) r_t0 = __builtin_amdgcn_s_memtime();
         if (isParam && xP) {
-          const double2 csA = *reinterpret_cast<const double2 *>(csc + 4 * pA);
-          const double2 csB = *reinterpret_cast<const double2 *>(csc + 4 * pB);
-          const double tA = csc[4 * pA + 2], tB = csc[4 * pB + 2];
+          // look-ahead: pair `tid` of the NEXT round is (a, b) in today's positions; its three elements after today's
+          // rotations, in float32 (the inputs are read as float64 and converted)
+          const float2 fA = *reinterpret_cast<const float2 *>(csc + 4 * pA + 2);     // (t, c0) of pair A
+          const float2 fB = *reinterpret_cast<const float2 *>(csc + 4 * pB + 2);
           const double2 dA = *reinterpret_cast<const double2 *>(Gc + (2 * pA) * ne + 2 * pA);
           const double bA = Gc[(2 * pA + 1) * ne + 2 * pA + 1];
           const double2 dB = *reinterpret_cast<const double2 *>(Gc + (2 * pB) * ne + 2 * pB);
@@ -656,26 +815,37 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
             r0 = dA;
             r1 = make_double2(dA.y, bA);
           }
-          const double na = ra ? fma(tA, dA.y, bA) : fma(-tA, dA.y, dA.x);
-          const double nb = rb ? fma(tB, dB.y, bB) : fma(-tB, dB.y, dB.x);
+          const float tA = fA.x, cA = fA.y, sA = fA.x * fA.y, tB = fB.x, cB = fB.y, sB = fB.x * fB.y;
+          const float aAx = (float)dA.x, aAy = (float)dA.y, aAb = (float)bA, aBx = (float)dB.x, aBy = (float)dB.y, aBb = (float)bB;
+          const float q0x = (float)r0.x, q0y = (float)r0.y, q1x = (float)r1.x, q1y = (float)r1.y;
+          const float na = ra ? fmaf(tA, aAy, aAb) : fmaf(-tA, aAy, aAx);
+          const float nb = rb ? fmaf(tB, aBy, aBb) : fmaf(-tB, aBy, aBx);
           // element (ra, rb) of R_A^T . blk . R_B
-          const double h0 = ra ? fma(csA.y, r0.x, csA.x * r1.x) : fma(csA.x, r0.x, -csA.y * r1.x);
-          const double h1 = ra ? fma(csA.y, r0.y, csA.x * r1.y) : fma(csA.x, r0.y, -csA.y * r1.y);
-          const double ng = rb ? fma(csB.y, h0, csB.x * h1) : fma(csB.x, h0, -csB.y * h1);
+          const float h0 = ra ? fmaf(sA, q0x, cA * q1x) : fmaf(cA, q0x, -sA * q1x);
+          const float h1 = ra ? fmaf(sA, q0y, cA * q1y) : fmaf(cA, q0y, -sA * q1y);
+          const float ng = rb ? fmaf(sB, h0, cB * h1) : fmaf(cB, h0, -sB * h1);
           if (stampRound) { asm volatile("" :: "v"(na), "v"(nb), "v"(ng)); r_t1 = __builtin_amdgcn_s_memtime(); }
-          const Rot r = jacobi_rot(na, nb, ng, kept2, abs2, p.svd_stop2);
-          if (stampRound) { asm volatile("" :: "v"(r.c), "v"(r.s)); r_t2 = __builtin_amdgcn_s_memtime(); }
-          double *o = k.dCS + ((cur ^ 1) * np + tid) * 4;
-          o[0] = r.c; o[1] = r.s; o[2] = r.t;
-          if (r.level >= 1) k.sFlag[0] = 1;
-          if (r.level >= 2) k.sFlag[1] = 1;
+          const RotT r = jacobi_rot_f32(na, nb, ng, fmaxf((float)kept2, kept_lo), (float)abs2, (float)p.svd_stop2);
+          if (stampRound) { asm volatile("" :: "v"(r.t), "v"(r.c0)); r_t2 = __builtin_amdgcn_s_memtime(); }
+          publish(k.dCS + ((cur ^ 1) * np + tid) * 4, r, round_idx + 1);
         }
+#ifdef TNML_EXP_FINE_STAMPS
+        const bool wst = p.stamps && stampAll && (tid & 63) == 0;
+        unsigned long long w_t0 = 0, w_t1 = 0, w_t2 = 0;
+        if (wst) w_t0 = __builtin_amdgcn_s_memtime();
+#endif
         if (isVwave && xV) {                                    // whole waves: every lane runs the shifts
-          const double2 cs = *reinterpret_cast<const double2 *>(csc + 4 * (vLaneOk ? vQ : 0));
+          const double2 tc = *reinterpret_cast<const double2 *>(csc + 4 * (vLaneOk ? vQ : 0));     // (t, c0) of pair Q
+#ifdef TNML_EXP_FINE_STAMPS
+          if (wst) { asm volatile("" :: "v"(tc.x), "v"(tc.y)); w_t1 = __builtin_amdgcn_s_memtime(); }
+#endif
+          const double cq = tc.y * rot_corr(tc.x, tc.y);
 #pragma unroll
           for (int r = 0; r < kVR; ++r) {
-            const double n11 = cs.x * vb[r][0] - cs.y * vb[r][1], n12 = cs.y * vb[r][0] + cs.x * vb[r][1];
-            const double n21 = cs.x * vb[r][2] - cs.y * vb[r][3], n22 = cs.y * vb[r][2] + cs.x * vb[r][3];
+            if (r >= vr) break;                                 // wave-uniform
+            // columns by R_Q: (v1, v2) -> c (v1 - t v2), c (t v1 + v2)
+            const double n11 = cq * fma(-tc.x, vb[r][1], vb[r][0]), n12 = cq * fma(tc.x, vb[r][0], vb[r][1]);
+            const double n21 = cq * fma(-tc.x, vb[r][3], vb[r][2]), n22 = cq * fma(tc.x, vb[r][2], vb[r][3]);
             if (np > 1) {
               const double t1 = dpp_f64<0x138>(n11), t2 = dpp_f64<0x138>(n21);      // top column of pair Q-1
               const double b1 = dpp_f64<0x138>(n12), b2 = dpp_f64<0x138>(n22);      // bottom column of pair Q-1
@@ -692,53 +862,71 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
           if (!itValid[u] || !xG) continue;
-          const double2 csq = *reinterpret_cast<const double2 *>(csc + itCsQ[u]);
-          const double2 csp = *reinterpret_cast<const double2 *>(csc + itCsP[u]);
+          const double2 tq = *reinterpret_cast<const double2 *>(csc + itCsQ[u]);      // (t, c0) of the column pair
+          const double2 tp = *reinterpret_cast<const double2 *>(csc + itCsP[u]);      // ... of the row pair
           const double *src = Gc + itSrc[u];
           const double2 r0 = *reinterpret_cast<const double2 *>(src);
           double2 r1 = *reinterpret_cast<const double2 *>(src + ne);
           if (itDiag[u]) r1.x = r0.y;                           // lower element of a diagonal block = its mirror
-          // rows by R_P^T, columns by R_Q
-          const double h11 = csp.x * r0.x - csp.y * r1.x, h12 = csp.x * r0.y - csp.y * r1.y;
-          const double h21 = csp.y * r0.x + csp.x * r1.x, h22 = csp.y * r0.y + csp.x * r1.y;
-          double n11 = csq.x * h11 - csq.y * h12, n12 = csq.y * h11 + csq.x * h12;
-          double n21 = csq.x * h21 - csq.y * h22, n22 = csq.y * h21 + csq.x * h22;
-          if (itDiag[u] && csq.y != 0.0) { n12 = 0.0; n21 = 0.0; }   // the annihilated element, exactly
+#ifdef TNML_EXP_FINE_STAMPS
+          if (wst && u == 0) { asm volatile("" :: "v"(r0.x), "v"(r1.y), "v"(tq.x), "v"(tp.y)); w_t1 = __builtin_amdgcn_s_memtime(); }
+#endif
+          // R_P^T . blk . R_Q = cP cQ [[1, -tP], [tP, 1]] . blk . [[1, tQ], [-tQ, 1]]: the tangents act first (they need no
+          // refinement), the product of the two cosines is formed meanwhile and multiplied in last
+          const double a11 = fma(-tp.x, r1.x, r0.x), a12 = fma(-tp.x, r1.y, r0.y);
+          const double a21 = fma(tp.x, r0.x, r1.x), a22 = fma(tp.x, r0.y, r1.y);
+          const double b11 = fma(-tq.x, a12, a11), b12 = fma(tq.x, a11, a12);
+          const double b21 = fma(-tq.x, a22, a21), b22 = fma(tq.x, a21, a22);
+          const double c00 = tp.y * tq.y, corr = rot_corr(tp.x, tp.y) * rot_corr(tq.x, tq.y);
+          double n11 = (b11 * c00) * corr, n12 = (b12 * c00) * corr, n21 = (b21 * c00) * corr, n22 = (b22 * c00) * corr;
+          if (itDiag[u] && tq.x != 0.0) { n12 = 0.0; n21 = 0.0; }   // the annihilated element, exactly
           Gn[itD11[u]] = n11; Gn[itD12[u]] = n12;
           if (!itDiag[u]) Gn[itD21[u]] = n21;                   // (n21 of a diagonal block is n12's mirror)
           Gn[itD22[u]] = n22;
         }
-        __syncthreads();
+#ifdef TNML_EXP_FINE_STAMPS
+        if (wst) {
+          asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(vb[0][0]), "v"(vb[1][3]) : "memory");
+          w_t2 = __builtin_amdgcn_s_memtime();
+        }
+#endif
+        lds_barrier();
+#ifdef TNML_EXP_FINE_STAMPS
+        if (wst) {
+          const unsigned long long w_t3 = __builtin_amdgcn_s_memtime();
+          p.stamps[56 + 16 + (tid >> 6)] = (double)(w_t2 - w_t0) + 1e-3 * (double)(wrank + 1) + 1e5 * (double)(w_t3 - w_t2);   // work + 1e5 * wait, role in the fraction
+        }
+#endif
         if (stampRound) {
           r_t3 = __builtin_amdgcn_s_memtime();
           p.stamps[14] = (double)(r_t1 - r_t0); p.stamps[15] = (double)(r_t2 - r_t1); p.stamps[16] = (double)(r_t3 - r_t2);
         }
         double *tsw = Gc; Gc = Gn; Gn = tsw;
         cur ^= 1;
+        last_big1 = max(last_big1, big_slot);
+        ++round_idx;
   };
   if (p.stamps && tid == 0) t_c1 = __builtin_amdgcn_s_memtime();
   if (n > 1) {
     kept2 = kept_scale(Gc);
-    if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
+    if (tid == 0) { k.sFlag[6] = 0; k.sFlag[7] = 0; }
     if (isParam) {                                   // rotations of the very first round
       const double2 top = *reinterpret_cast<const double2 *>(Gc + (2 * tid) * ne + 2 * tid);
-      const Rot r = jacobi_rot(top.x, Gc[(2 * tid + 1) * ne + 2 * tid + 1], top.y, kept2, abs2, p.svd_stop2);
-      double *o = k.dCS + (cur * np + tid) * 4;
-      o[0] = r.c; o[1] = r.s; o[2] = r.t;
-      if (r.level >= 1) k.sFlag[0] = 1;
-      if (r.level >= 2) k.sFlag[1] = 1;
+      const RotT r = jacobi_rot_f32((float)top.x, (float)Gc[(2 * tid + 1) * ne + 2 * tid + 1], (float)top.y,
+                                    fmaxf((float)kept2, kept_lo), (float)abs2, (float)p.svd_stop2);
+      publish(k.dCS + (cur * np + tid) * 4, r, 0);
     }
-    __syncthreads();
-    for (; sweeps < kJacobiMaxSweeps; ++sweeps) {
-      for (int rnd = 0; rnd < ne - 1; ++rnd)
-        jacobi_round(p.stamps && tid == 0 && sweeps == 0 && rnd == 7, true, true, true);
-      // the flags cover the rotations applied in the last ne-2 rounds plus the one prepared for the
-      // next round: any ne-1 consecutive rounds form a complete sweep
-      const int any_rot = k.sFlag[0], big_rot = k.sFlag[1];
-      __syncthreads();
-      if (!any_rot || !big_rot) { converged = 1; ++sweeps; break; }
-      if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
-      kept2 = kept_scale(Gc);
+    lds_barrier();
+    // The iteration ends as soon as ne - 1 consecutive rounds -- any such window is a complete sweep over all pairs --
+    // applied no big rotation: quadratic convergence then leaves off-diagonals of relative size ~svd_stop2, exactly the
+    // guarantee of "a whole sweep without a big rotation", but the window need not start at a sweep boundary (it saves
+    // about a third of a sweep per decomposition once the chain has settled).
+    for (; sweeps < kJacobiMaxSweeps && !converged; ++sweeps) {
+      for (int rnd = 0; rnd < ne - 1; ++rnd) {
+        jacobi_round(p.stamps && tid == 0 && sweeps == 0 && rnd == 7, true, true, true, sweeps == 0 && rnd == 7);
+        if (round_idx - last_big1 >= ne - 1) { converged = 1; break; }      // block-uniform
+      }
+      if (!converged) kept2 = kept_scale(Gc);
     }
   } else {
     converged = 1;
@@ -749,7 +937,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 #pragma unroll
     for (int r = 0; r < kVR; ++r) {
       const int P = vP0 + r;
-      if (P < np) {
+      if (r < vr && P < np) {
         *reinterpret_cast<double2 *>(V + (2 * P) * ne + 2 * vQ) = make_double2(vb[r][0], vb[r][1]);
         *reinterpret_cast<double2 *>(V + (2 * P + 1) * ne + 2 * vQ) = make_double2(vb[r][2], vb[r][3]);
       }
@@ -759,7 +947,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 
   // ---- phase 8: eigenvalues = diag(G), descending order -------------------------------------------
   for (int j = tid; j < n; j += NT) k.dLam[j] = __builtin_amdgcn_ldexp(fmax(Gc[j * ne + j], 0.0), sc_exp);
-  __syncthreads();
+  lds_barrier();
   if (use_chol) {
     // back from the eigenvectors u of G' = L^T L to those of G: v = L u / sqrt(lambda) (columns stay at their positions)
     small_gemm_f64(1, n, n, n,
@@ -770,7 +958,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
                      Gn[i * ne + j] = ls > 1e-300 ? v / sqrt(ls) : 0.0;
                    });
     V = Gn;
-    __syncthreads();
+    lds_barrier();
   }
   for (int j = tid >> 6; j < n; j += NT >> 6) {           // one wave per entry: lane i votes "i sorts before j" (n <= 64)
     const int i = tid & 63;
@@ -784,9 +972,9 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   }
   if (tid == 0) {
     if (p.counters) {
-      atomicAdd(p.counters, (unsigned long long)sweeps);
+      atomicAdd(p.counters, (unsigned long long)sweeps);                 // started sweeps (the last one may be partial)
       atomicAdd(p.counters + 1, 1ull);
-      atomicAdd(p.counters + 2, (unsigned long long)sweeps * (unsigned long long)(ne - 1));
+      atomicAdd(p.counters + 2, (unsigned long long)round_idx);
     }
     if (!converged) atomicOr(p.status, 2);
     if (p.dbg) {
@@ -795,7 +983,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       sc[4] = (double)n;
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   if (p.stamps && tid == 0) t_c2b = __builtin_amdgcn_s_memtime();
   // ---- adaptive truncation (not reference behaviour: the reference computes this index and never uses it,
@@ -816,7 +1004,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       k.sFlag[2] = me;
       if (p.m_out) *p.m_out = me;
     }
-    __syncthreads();
+    lds_barrier();
     mk = k.sFlag[2];
     if (!p.left_dir) { ob_s_h = D * mk; ob_s_d = mk; } else { oa_s_d = mk * L; oa_s_g = D * mk * L; }
   }
@@ -829,7 +1017,8 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     k.dSq[sp] = sq;
     k.dSq[ne + sp] = ok ? 1.0 / sq : 0.0;
   }
-  __syncthreads();
+  lds_barrier();
+  YSTAMP(6);
   // short-side factor: q_j * sigma_j^(1/2)   (rows kk over waves, kept columns over lanes: no divisions)
   for (int kk = tid >> 6; kk < n; kk += NT >> 6)
    for (int sp = tid & 63; sp < mk; sp += 64) {
@@ -841,6 +1030,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     } else {                                // kk = column index (dk1*g + g_)*L + l -> ahead core
       const int l = kk % L, q = kk / L;
       p.out_ahead[sp * p.oa_s_m + (q / g) * oa_s_d + (q % g) * oa_s_g + l] = v;
+      if (p.tail_prep) k.sLab2[sp * c + kk] = v;
     }
    }
   // long-side factor: (W q_j) / sigma_j^(1/2); columns s', inner index the short one
@@ -851,7 +1041,9 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
                    [&](int l, int kk, int sp) { return V[kk * ne + k.sOrd[sp]]; },
                    [&](int l, int qq, int sp, double acc) {
                      const int dk1 = qq >= g ? 1 : 0;                     // D == 2
-                     p.out_ahead[sp * p.oa_s_m + dk1 * oa_s_d + (qq - dk1 * g) * oa_s_g + l] = (float)(acc * k.dSq[ne + sp]);
+                     const float v = (float)(acc * k.dSq[ne + sp]);
+                     p.out_ahead[sp * p.oa_s_m + dk1 * oa_s_d + (qq - dk1 * g) * oa_s_g + l] = v;
+                     if (p.tail_prep) k.sLab2[sp * c + qq * L + l] = v;
                    });
   } else {
     // long index = behind group x = (h_, dk) = h_ * D + dk: dk is the batch, rows are h_
@@ -864,23 +1056,56 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
                      p.out_behind[h_ * ob_s_h + dk * ob_s_d + sp * p.ob_s_m] = v;
                    });
   }
-  __syncthreads();
+  lds_barrier();
 
   if (p.stamps && tid == 0) t_c2c = __builtin_amdgcn_s_memtime();
   // ---- phase 10: behind norm environment of the next step ------------------------------------------
+  // tail region (phase 12) inside the Jacobi buffers, dead from here on
+  const int g2 = p.g2, RW2 = D * D * g2 * L, Bs2 = mk * RW2, QW2 = D * g2;
+  double *tT = k.Z, *tNh = tT + Bs2;
+  float *tB = (float *)(tNh + (((size_t)m * m + 1) & ~(size_t)1));
+  const float *tPl = k.sPl2;
+  const double *tNg = k.dNg2;
+  YSTAMP(10);
   if (p.Nh_new) {
     // T2[h_, (d, s'')] = sum_h' Nh[h_, h'] Cb[h', (d, s'')]
     const int DM = D * mk;
-    small_gemm_f64(1, h, DM, h,
-                   [&](int, int i, int kk) { return k.dNh[i * h + kk]; },
-                   [&](int, int kk, int j) { return (double)k.sCb[kk * DM + j]; },
-                   [&](int, int i, int j, double v) { k.dT2[i * DM + j] = v; });
-    __syncthreads();
+#ifdef TNML_EXP_FINE_STAMPS
+    // experiment: the same product twice through the same code -- the second pass finds its instructions in the cache
+    for (int rep = 0; rep < (p.stamps ? 2 : 1); ++rep) {
+      mm_lds(1, h, DM, h, k.dNh, 0, h, 1, k.sCb, 0, DM, 1, [&](int, int i, int j, double v) { k.dT2[i * DM + j] = v; });
+      if (rep == 0) { YSTAMP(8); }
+      lds_barrier();
+    }
+    YSTAMP(11);
+#else
+    mm_lds(1, h, DM, h, k.dNh, 0, h, 1, k.sCb, 0, DM, 1, [&](int, int i, int j, double v) { k.dT2[i * DM + j] = v; });
+    lds_barrier();
+#endif
     // Nh_new[s', s''] = sum_{(h_, d)} Cb[(h_, d), s'] T2[(h_, d), s'']
-    small_gemm_f64(1, mk, mk, h * D,
-                   [&](int, int i, int kk) { return (double)k.sCb[kk * mk + i]; },
-                   [&](int, int kk, int j) { return k.dT2[kk * mk + j]; },
-                   [&](int, int i, int j, double v) { p.Nh_new[i * mk + j] = v; });
+    mm_lds(1, mk, mk, h * D, k.sCb, 0, 1, mk, k.dT2, 0, mk, 1,
+           [&](int, int i, int j, double v) { p.Nh_new[i * mk + j] = v; if (p.tail_prep) tNh[i * mk + j] = v; });
+  }
+  // ---- phase 12: merged tensor and L2 term of the NEXT step (the arithmetic of prep_slice_block, small_gemm_device.h) ------
+  YSTAMP(12);
+  if (p.tail_prep) {
+    lds_barrier();
+    mm_lds(L, mk * D, QW2, g, k.sLab2, 1, g * L, L, tPl, 0, QW2, 1,
+           [&](int l, int i, int j, double v) {
+             const float fv = (float)v;
+             tB[(i * QW2 + j) * L + l] = fv;
+             p.prepB[(size_t)(i * QW2 + j) * L + l] = fv;
+           });
+    YSTAMP(13);
+    if (p.l2_flag) {
+      lds_barrier();
+      mm_lds(1, mk, RW2, mk, tNh, 0, 1, mk, tB, 0, RW2, 1, [&](int, int i, int j, double v) { tT[i * RW2 + j] = v; });
+      YSTAMP(14);
+      lds_barrier();
+      mm_lds(L, Bs2 / (g2 * L), g2, g2, tT, 1, g2 * L, L, tNg, 0, g2, 1,
+             [&](int l, int i, int j, double v) { p.prepG[(size_t)(i * g2 + j) * L + l] = v; });
+      YSTAMP(15);
+    }
   }
 
   if (p.stamps && tid == 0) {
@@ -896,6 +1121,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     p.stamps[37] = (double)(t_p[3] - t_x[2]); p.stamps[38] = (double)(t_x[3] - t_p[3]); p.stamps[39] = (double)(t_x[4] - t_x[3]);
     p.stamps[40] = (double)(t_p[4] - t_x[4]);
     p.stamps[48] = use_chol ? (double)(t_x[6] - t_x[5]) : 0.0; p.stamps[49] = use_chol ? (double)(t_x[7] - t_x[6]) : 0.0;
+    for (int i = 0; i < 16; ++i) p.stamps[56 + i] = t_y[i] ? (double)(t_y[i] - t_c0) : 0.0;      // cycles since the kernel's start
 #endif
     p.stamps[6] = (double)(t_c2b - t_c2); p.stamps[7] = (double)(t_c2c - t_c2b); p.stamps[8] = (double)(t_c3 - t_c2c);
   }
@@ -912,12 +1138,12 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // timing experiment (tools/build_exp.sh): ne-1 rounds each with parts of the round switched off, on the
   // dead Jacobi buffers; cycles per round land in stamps[41..47]
   if (p.stamps && n > 2) {
-    __syncthreads();
+    lds_barrier();
     for (int variant = 0; variant < 7; ++variant) {
       // bit 0: parameter threads, bit 1: G items, bit 2: V blocks
       const int mask = variant == 0 ? 7 : variant;          // 0 -> everything; 1 P; 2 G; 3 P+G; 4 V; 5 P+V; 6 G+V
       const bool xP = mask & 1, xG = mask & 2, xV = mask & 4;
-      __syncthreads();
+      lds_barrier();
       const unsigned long long e0 = __builtin_amdgcn_s_memtime();
       for (int rnd = 0; rnd < ne - 1; ++rnd) jacobi_round(false, xP, xG, xV);
       const unsigned long long e1 = __builtin_amdgcn_s_memtime();

@@ -100,9 +100,12 @@ struct tnml_ctx {
   unsigned *sync = nullptr;
   // pipelined step (wide_pipe_device.h): partial / group / reduced pre-gradients, arrival counters, B_new flag
   bool pipe_enabled = true;                  // tnml_set_step_pipeline
+  bool tail_prep = false;                    // workgroup 0 prepares the next step's merged tensor / L2 term at the end of its launch
   float *zslabs = nullptr, *gslabs = nullptr, *zred = nullptr;
   unsigned *pipe_cnt = nullptr;              // [0..15] group counters, [16] top counter, [17] flag
   int zstride = 0, pipe_nwide = 0, pipe_tpw = 1, pipe_ngroups = 0;
+  bool prep_valid = false;                   // prepB / prepG hold the merged tensor and L2 term of relative step prep_k (tail of the previous launch)
+  int prep_k = -1, prep_left = 0, prep_l2 = 0;
   bool Z_valid = false;                      // zred holds the pre-gradient of relative step Z_k of a sweep in direction Z_left
   int Z_k = -1, Z_left = 0, Z_act = 0, Z_loss = 0;
   float Z_T = 0.f;
@@ -240,7 +243,7 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   c->metrics_cap = N;
   HIP_TRY(hipMalloc(&c->metrics, (size_t)c->metrics_cap * 2 * sizeof(float)));
   HIP_TRY(hipMalloc(&c->scal, 64 * sizeof(float)));
-  c->dbg_elems = 4 * c->bmax + kDbgSigma + 64;   // 4 tensors, sigma[kDbgSigma], 5 scalars, stamps
+  c->dbg_elems = 4 * c->bmax + kDbgSigma + 128;   // 4 tensors, sigma[kDbgSigma], 5 scalars, stamps
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
   HIP_TRY(hipMalloc(&c->status, 2 * sizeof(int)));      // [0] status word, [1] kept rank of the last adaptive step
   HIP_TRY(hipMemsetAsync(c->status, 0, 2 * sizeof(int), c->stream));
@@ -369,6 +372,7 @@ extern "C" int tnml_set_cores(tnml_ctx *c, const float *flat, size_t n_floats, c
   c->f_current = false;
   c->Bnew_valid = false;
   c->Z_valid = false;
+  c->prep_valid = false;
   return TNML_OK;
 }
 
@@ -415,6 +419,7 @@ extern "C" int tnml_scale_cores(tnml_ctx *c, double factor) {
   c->f_current = false;
   c->Bnew_valid = false;
   c->Z_valid = false;
+  c->prep_valid = false;
   return TNML_OK;
 }
 
@@ -1005,15 +1010,41 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
         if (c->comm) NCCL_TRY(ncclAllReduce(c->zred, c->zred, wpro.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
         if (wpro.do_f) c->f_current = true;
       }
-      n.fused = 1; n.nred = 0; n.prep_ready = 0; n.wait_count = kD * kD; n.sync = c->sync; n.red_out = nullptr;
+      // merged tensor / L2 term of this step: from the tail of the previous launch if it prepared them, else from the
+      // slice workgroups this launch carries
+      const bool have_prep = c->prep_valid && c->prep_k == k && c->prep_left == left_dir && c->prep_l2 == (l2_flag ? 1 : 0);
+      c->prep_valid = false;
+      n.fused = 1; n.nred = 0; n.sync = c->sync; n.red_out = nullptr;
+      n.prep_ready = have_prep ? 1 : 0;
+      n.wait_count = have_prep ? 0 : kD * kD;
+      // ... and this launch's tail prepares the next step's, when that step exists and will run pipelined in LDS
+      // (measured, round 2: the three products of that preparation cost workgroup 0 23 k cycles at the end of its launch and
+      // save it 16 k cycles of waiting for the slice workgroups at the start of the next: off by default)
+      if (wp.do_z && c->tail_prep) {
+        const int p2 = left_dir ? p - 1 : p + 1;
+        const int g2 = wp.gn;
+        const int m2 = tnml_trunc_rank(trunc_policy, left_dir, p2, N, left_dir ? g2 : m, D, left_dir ? m : g2, L, c->Mpol);
+        const size_t bs2 = (size_t)m * D * D * g2 * L;
+        if (m2 > 0 && bs2 <= c->bmax && narrow_path(c, m, g2, g, L, m2) == 0 &&
+            narrow_lds_bytes(h, g, s, L, m, g2) <= 160 * 1024) {
+          n.tail_prep = 1; n.g2 = g2;
+          const int site2 = left_dir ? p - 1 : p + 2;              // relative site k+2
+          n.pl2.base = c->core_slot(site2); n.pl2.n_in = g; n.pl2.n_out = g2;
+          if (!left_dir) { n.pl2.s_in = D * g2; n.pl2.s_d = g2; n.pl2.s_out = 1; }
+          else { n.pl2.s_in = 1; n.pl2.s_d = g; n.pl2.s_out = D * g; }
+          const int as2 = left_dir ? p - 2 : p + 3;
+          n.Ng2 = (l2_flag && as2 >= 0 && as2 <= N - 1) ? c->norm_slot(nahe, as2) : nullptr;
+          c->prep_valid = true; c->prep_k = k + 1; c->prep_left = left_dir; c->prep_l2 = l2_flag ? 1 : 0;
+        }
+      }
       n.pipe = 1; n.z_first = (k == 0); n.z_rows = wp.hprev * D;
       n.zsize = (k == 0 ? 1 : n.z_rows) * D * D * g * L;
       n.zred = c->zred; n.red = c->zred; n.zcore = wp.ext_core;
       n.flag = c->pipe_cnt + 17; n.token = ++c->token;
       wp.token = n.token;
-      wp.wg0 = 1 + kD * kD;
-      size_t lds = std::max(narrow_lds_bytes(h, g, s, L, m), wide_pipe_lds_bytes(wp));
-      lds = std::max(lds, prep_slice_lds_bytes(h, g, s, L));
+      wp.wg0 = 1 + n.wait_count;
+      size_t lds = std::max(narrow_lds_bytes(h, g, s, L, m, n.tail_prep ? n.g2 : 0), wide_pipe_lds_bytes(wp));
+      if (!have_prep) lds = std::max(lds, prep_slice_lds_bytes(h, g, s, L));
       if (lds > 160 * 1024) return fail(TNML_ERR_ARG, "internal: pipelined step needs %zu bytes of LDS", lds);
       prof_begin(c);
       launch_step_pipe(n, wp, lds, c->stream);
@@ -1023,6 +1054,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       c->Z_valid = wp.do_z != 0; c->Z_k = k + 1; c->Z_left = left_dir; c->Z_act = act_fn; c->Z_loss = loss_fn; c->Z_T = T;
     } else {
       c->Z_valid = false;
+      c->prep_valid = false;
       // ---- wide kernel -----------------------------------------------------------------------
       WideParams w{};
       w.b = c->b; w.b_pad = c->b_pad; w.L = L;
@@ -1239,9 +1271,9 @@ extern "C" int tnml_l2_term(tnml_ctx *c, const float *B_canon, int left_dir, flo
   const bool dbg_was = c->debug;
   c->debug = true;
   size_t nn = 0;
-  double sc[64];
+  double sc[128];
   rc = tnml_get_step_debug(c, TNML_DBG_L2_GRAD, grad_canon, capacity, &nn);
-  if (!rc) rc = tnml_get_step_debug(c, TNML_DBG_L2, sc, 64, &nn);
+  if (!rc) rc = tnml_get_step_debug(c, TNML_DBG_L2, sc, 128, &nn);
   c->debug = dbg_was;
   if (rc) return rc;
   *loss = sc[0];
@@ -1328,6 +1360,7 @@ extern "C" int tnml_set_step_pipeline(tnml_ctx *c, int on) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   c->pipe_enabled = on != 0;
   c->Z_valid = false;
+  c->prep_valid = false;
   return TNML_OK;
 }
 
@@ -1359,9 +1392,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
   if (c->last_bsize <= 0) return fail(TNML_ERR_STATE, "no step has run yet");
   HIP_TRY(hipSetDevice(c->device));
   const size_t Bs = c->last_bsize;
-  std::vector<double> hbuf(4 * Bs + kDbgSigma + 64);   // tensors, sigma, 5 scalars, 14 stamps
+  std::vector<double> hbuf(4 * Bs + kDbgSigma + 128);   // tensors, sigma, 5 scalars, stamps
   HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, (4 * Bs + kDbgSigma + 5) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + kDbgSigma + 5, c->dbg + 4 * c->bmax + kDbgSigma + 5, 51 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + kDbgSigma + 5, c->dbg + 4 * c->bmax + kDbgSigma + 5, 115 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   auto tensor_out = [&](size_t block) -> int {
     if (capacity < Bs) return fail(TNML_ERR_ARG, "capacity too small");
@@ -1389,9 +1422,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
       if (n_out) *n_out = c->last_n;
       return TNML_OK;
     case TNML_DBG_L2:
-      if (capacity < 56) return fail(TNML_ERR_ARG, "capacity too small");
-      memcpy(out, hbuf.data() + 4 * Bs + kDbgSigma, 56 * sizeof(double));
-      if (n_out) *n_out = 56;
+      if (capacity < 120) return fail(TNML_ERR_ARG, "capacity too small");
+      memcpy(out, hbuf.data() + 4 * Bs + kDbgSigma, 120 * sizeof(double));
+      if (n_out) *n_out = 120;
       return TNML_OK;
   }
   return fail(TNML_ERR_ARG, "unknown debug selector %d", what);

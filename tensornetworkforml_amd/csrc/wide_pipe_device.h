@@ -23,6 +23,7 @@
 #pragma once
 #include "tnml_internal.h"
 #include "act_device.h"
+#include "jacobi_device.h"
 
 namespace tnml {
 
@@ -154,7 +155,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
     const int tile = wg + tt * p.nwide;
     if (tile >= p.ntiles) break;            // block-uniform
     const int s0 = tile * kTS;
-    if (tt > 0) __syncthreads();            // the previous tile's operand arrays are dead
+    if (tt > 0) lds_barrier();            // the previous tile's operand arrays are dead
     // ---- stage 1: everything that does not need B_new(j) ------------------------------------------------------------
     for (int e = tid; e < 4 * kTS * kD; e += NT) {
       const int which = e / (kTS * kD), rr = e % (kTS * kD);
@@ -176,7 +177,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
         w.sE[hn * kPTSP + sl] = hn < hj ? ((p.Ecur && !p.first) ? p.Ecur[(size_t)hn * p.b_pad + s0 + sl] : 1.0f) : 0.f;
       }
     }
-    __syncthreads();
+    lds_barrier();
     const float *sXm = w.sX, *sXj = w.sX + kTS * kD, *sXp = w.sX + 2 * kTS * kD, *sXq = w.sX + 3 * kTS * kD;
     if (p.do_ext) {
       for (int e = tid; e < dm.KA * kTS; e += NT) {               // P''[i''][s]
@@ -185,7 +186,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
         if (i < hprev * kD) v = (p.first_ext ? 1.0f : p.Eprev[(size_t)(i >> 1) * p.b_pad + s0 + sl]) * sXm[sl * kD + (i & 1)];
         w.sPpp[i * kPTSP + sl] = v;
       }
-      __syncthreads();
+      lds_barrier();
       const int HT = dm.EH / 16;
       for (int cidx = wave; cidx < HT * ST; cidx += NWV) {        // E_j[hn][s] = sum_i'' A[i''][hn] P''[i''][s]
         const int ht = cidx / ST, st = cidx % ST;
@@ -201,7 +202,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
           if (hn < hj) p.Ecur[(size_t)hn * p.b_pad + s0 + st * 16 + r] = acc[reg];
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
     for (int e = tid; e < dm.IP * kTS; e += NT) {                 // P'[i][s] = E_j[h][s] x_j[s][d]   (first: the scalar 1)
       const int sl = e % kTS, i = e / kTS;
@@ -242,13 +243,13 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
         }
         flag_seen = true;
       }
-      __syncthreads();                                            // the poll is over; P', Q', Qn are complete
+      lds_barrier();                                            // the poll is over; P', Q', Qn are complete
       const int rowlen = nJ * L;
       if (tt == 0) {                                              // B'[i][(jj, l)] at the odd row stride, zero padded
         for (int i = wave; i < dm.IP; i += NWV)
           for (int x = lane; x < dm.RS; x += 64)
             w.sBp[i * dm.RS + x] = (i < nI && x < rowlen) ? (p.wait_flag ? ld_sc1(p.Bnew + i * rowlen + x) : p.Bnew[i * rowlen + x]) : 0.f;
-        __syncthreads();
+        lds_barrier();
       }
       const int ITF = dm.IP / 16;
       for (int cidx = wave; cidx < L * ST * ITF; cidx += NWV) {   // T_l[i][s] = sum_jj B'_l[i][jj] Q'[jj][s];  f += P' . T
@@ -268,7 +269,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
         facc += __shfl_xor(facc, 32);
         if (q == 0) w.sFp[(it * L + l) * kTS + st * 16 + r] = facc;
       }
-      __syncthreads();
+      lds_barrier();
       for (int e = tid; e < L * kTS; e += NT) {                   // partial sums in block order (deterministic)
         float t = 0.f;
         for (int it = 0; it < ITF; ++it) t += w.sFp[it * L * kTS + e];
@@ -276,7 +277,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
         p.f[(size_t)(e / kTS) * p.b_pad + s0 + (e % kTS)] = t;
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (!p.do_z) continue;
     // ---- stage 3: activation, metrics, loss derivative (one thread per sample) ------------------------------------------
     if (tid < kTS) {
@@ -290,7 +291,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
       }
       w.sMet[tid] = (float)m_cor; w.sMet[kTS + tid] = m_abs; w.sMet[2 * kTS + tid] = (float)m_nf;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 3) {
       float t = 0.f;
 #pragma unroll
@@ -308,7 +309,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
         if (ii < nI * kD) v = w.sGl[l * kTS + sl] * w.sPp[(ii >> 1) * kPTSP + sl] * sXp[sl * kD + (ii & 1)];
         w.sPg[((size_t)l * dm.I3 + ii) * kPTSP + sl] = v;
       }
-    __syncthreads();
+    lds_barrier();
     // ---- stage 5: Z_l[ii][jn] += sum_s Pg_l[ii][s] Qn[jn][s] -------------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < kMaxZT; ++u) {
@@ -347,11 +348,11 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
   const int n = p.zsize + kMetricSlots;
   __shared__ unsigned sTicket;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  lds_barrier();
   const int grp = wg / p.gsz;
   const int g_lo = grp * p.gsz, g_n = min(p.gsz, p.nwide - g_lo);
   if (tid == 0) sTicket = __hip_atomic_fetch_add(p.gcnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
+  lds_barrier();
   if (sTicket != (unsigned)(g_n - 1)) return;                     // not the last arriver of its group
   // The last arriver reads what the other workgroups stored: one agent-scope acquire (invalidates this CU's L1 and the
   // non-coherent lines of its L2), drained, then a barrier, then ordinary 16-byte loads, all of an element's summands
@@ -361,7 +362,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
+    lds_barrier();
   };
   auto sum_slabs = [&](const float *src, int count, float *dst, bool publish) {
     const int n4 = (n + 3) / 4;
@@ -385,9 +386,9 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
   sum_slabs(p.slabs + (size_t)g_lo * p.slab_stride, g_n, p.gslabs + (size_t)grp * p.slab_stride, true);
   if (tid == 0) __hip_atomic_store(p.gcnt + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  lds_barrier();
   if (tid == 0) sTicket = __hip_atomic_fetch_add(p.tcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
+  lds_barrier();
   if (sTicket != (unsigned)(p.ngroups - 1)) return;               // not the last group
   // level 2: the group sums in group order -> the reduced tensor the next launch reads (ordinary stores: the kernel
   // boundary publishes them)

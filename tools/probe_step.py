@@ -45,6 +45,11 @@ def stamp_line(tag, sc):
         print('   fine stamps: phase-4 loop %d / block sums %d / update loop %d / barrier after update %d | zero fill+barrier %d / gram GEMM %d / symmetrise+tables %d' % tuple(sc[39:46]))
     if len(sc) > 54 and sc[53] > 0:
         print('   Cholesky step: factorisation %d / L^T L + symmetrise %d cycles' % (sc[53], sc[54]))
+    if len(sc) > 84 and sc[61] > 0:
+        names = ['loads issued', 'lds stored', 'barrier', 'contraction', 'prep loaded', '', 'sigma pow+barrier', 'gather+barrier', 'T2 gemm first pass', '', 'phase10 start', 'T2 gemm', 'Nh_new gemm', "B' gemm", 'T gemm', "G' gemm"]
+        print('   y-stamps (cycles since kernel start):', ' | '.join('%s %d' % (names[i], sc[61 + i]) for i in range(16) if names[i] and sc[61 + i] > 0))
+    if len(sc) > 93:
+        print('   per wave (work cycles, barrier wait, role rank): ' + ' '.join('w%d:%d/%d/r%d' % (i, int(sc[77 + i] % 1e5), int(sc[77 + i] // 1e5), round((sc[77 + i] % 1) * 1e3) - 1) for i in range(16)))
     if len(sc) > 13:
         print('   post split: sort %d / cores %d / norm env + metrics %d cycles' % (sc[11], sc[12], sc[13]))
 
