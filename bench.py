@@ -226,10 +226,11 @@ def main():
         if dist is not None:
             dt = dist.max_float(dt)
         sweep_ms, n_launch = ctx.profile_get(4)
+        cnt = ctx.counters()
         _, n_steps_pipe = ctx.profile_get(5)
         ctx.profile_enable(0)
         sw_tot, n_svd, rounds_tot = ctx.svd_stats(reset=True)
-        return dict(dt=dt, sweep_ms=sweep_ms, launches=n_launch, pipe_steps=n_steps_pipe,
+        return dict(dt=dt, sweep_ms=sweep_ms, launches=n_launch, pipe_steps=n_steps_pipe, counters=cnt,
                     sweeps_per_svd=sw_tot / max(n_svd, 1), rounds_per_svd=rounds_tot / max(n_svd, 1))
 
     for _ in range(args.warmup):
@@ -293,6 +294,8 @@ def main():
                       'sweep_only_steps_per_s': sweep_steps / max(1e-3 * main_run['sweep_ms'], 1e-9),
                       'steps_per_s_incl_h2d': (N - 1) / (dt / args.steps + 1e-3 * h2d_ms)},
         'final_accuracy': float(met[-1, 0]),
+        # the library's own account of the timed passes (tnml_get_counters: from the bond dimensions of every step that ran)
+        'counters': main_run['counters'],
         # the SVD is iterative: how much work the timed passes actually contained
         'jacobi': {'sweeps_per_svd': main_run['sweeps_per_svd'], 'rounds_per_svd': main_run['rounds_per_svd'],
                    'svd_stop2': args.svd_stop if args.svd_stop is not None else 1e-6},

@@ -177,7 +177,7 @@ int tnml_set_sync_interval(tnml_ctx *ctx, int n_steps);
  * workgroup's LDS when the merged tensor fits (min(rows, cols) <= 64 and <= 160 KB of LDS: bond <= 32 at
  * two labels) and through HBM-resident kernels otherwise (min(rows, cols) <= 128: bond 50 with ten labels).
  * force_large = 1 sends every step down the second path (tests, diagnostics); 0 restores the automatic
- * choice.  Environment variable TNML_NARROW=big does the same for a whole process. */
+ * choice. */
 int tnml_set_narrow_path(tnml_ctx *ctx, int force_large);
 
 /* TNML_TRUNC_ADAPTIVE (not reference behaviour): tensor_svd computes the cumulative share of the singular
@@ -216,6 +216,12 @@ int tnml_timer_stop(tnml_ctx *ctx, double *elapsed_ms);
 int tnml_profile_enable(tnml_ctx *ctx, int on);
 int tnml_profile_get(tnml_ctx *ctx, int which, double *ms, long long *launches);
 int tnml_profile_reset(tnml_ctx *ctx);
+/* Work done since the last tnml_profile_reset, computed from the dimensions of every step that ran:
+ *   out8 = {sweep steps, algorithmic bytes of those steps (4 b (2h + g + 3D + 2L + 1) each: environments, features, f, labels),
+ *           algorithmic flops (4 b D^2 h g L + 2 b D h^2 each), forward calls, algorithmic bytes of those forwards,
+ *           kernel launches of the sweeps, single-launch (pipelined) steps among them,
+ *           device ms inside the sweeps (0 unless tnml_profile_enable(ctx, 2) was on; read it through tnml_profile_get(4) first)} */
+int tnml_get_counters(tnml_ctx *ctx, double *out8);
 /* always-on counters of the Jacobi SVD since the last reset:
  *   out3 = {total sweeps, number of SVDs, total rounds (one barrier each)} */
 int tnml_svd_stats(tnml_ctx *ctx, int reset, double *out3);

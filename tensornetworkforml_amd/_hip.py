@@ -27,7 +27,7 @@ SYMBOLS = [
     'tnml_get_step_debug', 'tnml_l_pos', 'tnml_batch', 'tnml_timer_start', 'tnml_timer_stop',
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
     'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict', 'tnml_set_trunc_threshold',
-    'tnml_set_sync_interval', 'tnml_set_step_pipeline', 'tnml_stage_batch', 'tnml_select_batch',
+    'tnml_set_sync_interval', 'tnml_set_step_pipeline', 'tnml_stage_batch', 'tnml_select_batch', 'tnml_get_counters',
 ]
 
 
@@ -95,6 +95,7 @@ def lib():
         L.tnml_set_step_pipeline.argtypes = [vp, C.c_int]
         L.tnml_stage_batch.argtypes = [vp, C.c_int, f32p, i32p, C.c_int]
         L.tnml_select_batch.argtypes = [vp, C.c_int]
+        L.tnml_get_counters.argtypes = [vp, f64p]
         L.tnml_svd_split.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f64p]
         _lib = L
     return _lib
@@ -378,6 +379,13 @@ class Context:
         out = (C.c_double * 3)()
         _chk(lib().tnml_svd_stats(self._h, int(bool(reset)), out))
         return out[0], out[1], out[2]
+
+    def counters(self):
+        """Work since the last profile_reset: dict of sweep steps, algorithmic bytes / flops, forwards, launches, device ms."""
+        out = (C.c_double * 8)()
+        _chk(lib().tnml_get_counters(self._h, out))
+        keys = ('sweep_steps', 'algorithmic_bytes', 'algorithmic_flops', 'forwards', 'forward_bytes', 'launches', 'pipelined_steps', 'sweep_device_ms')
+        return dict(zip(keys, [float(v) for v in out]))
 
     def profile_get(self, which):
         ms, n = C.c_double(), C.c_longlong()

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
   double *G0 = (double *)smem_raw, *G1 = G0 + 4 * (size_t)nblk;
   double *dCS = G1 + 4 * (size_t)nblk;            // [2][np][4]
   double *dRed = dCS + 8 * (size_t)np;            // 64
-  int *sPi = (int *)(dRed + 64), *sPiInv = sPi + ne, *sFlag = sPiInv + ne;
+  int *sPi = (int *)(dRed + 64), *sPiInv = sPi + ne, *sFlag = sPiInv + ne;     // sFlag[2..3]: round index + 1 of the last big rotation
 
   // load + trace
   double trp = 0.0;
@@ -265,20 +265,23 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
   double kept2 = 0.0;
   if (n > 1) {
     kept2 = kept_scale(Gc);
-    if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; }
+    if (tid == 0) { sFlag[2] = 0; sFlag[3] = 0; }
     if (isParam) {
       const int sl = 4 * blk_index(tid, tid, np);
       const Rot r = jacobi_rot(Gc[sl], Gc[sl + 3], Gc[sl + 1], kept2, abs2, a.stop2);
       double *o = dCS + (cur * np + tid) * 4;
       o[0] = r.c; o[1] = r.s; o[2] = r.t;
       a.rotlog[tid] = make_double2(r.c, r.s);
-      if (r.level >= 1) sFlag[0] = 1;
-      if (r.level >= 2) sFlag[1] = 1;
+      if (r.level >= 2) sFlag[2] = 1;                // applied in round 0
     }
     __syncthreads();
-    for (; sweeps < kJacobiMaxSweeps; ++sweeps) {
+    // sliding window, as in the in-LDS kernel (kernels_narrow.hip phase 7): stop as soon as ne - 1 consecutive rounds applied no
+    // big rotation
+    int last_big1 = 0;
+    for (; sweeps < kJacobiMaxSweeps && !converged; ++sweeps) {
       for (int rnd = 0; rnd < ne - 1; ++rnd) {
         const double *csc = dCS + cur * np * 4;
+        const int big_slot = sFlag[2 + (rounds & 1)];
         if (isParam) {
           const double2 csA = *reinterpret_cast<const double2 *>(csc + 4 * pA);
           const double2 csB = *reinterpret_cast<const double2 *>(csc + 4 * pB);
@@ -309,8 +312,7 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
           double *o = dCS + ((cur ^ 1) * np + tid) * 4;
           o[0] = r.c; o[1] = r.s; o[2] = r.t;
           a.rotlog[(size_t)(rounds + 1) * np + tid] = make_double2(r.c, r.s);
-          if (r.level >= 1) sFlag[0] = 1;
-          if (r.level >= 2) sFlag[1] = 1;
+          if (r.level >= 2) sFlag[2 + ((rounds + 1) & 1)] = rounds + 2;
         }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
@@ -333,12 +335,10 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
         double *tsw = Gc; Gc = Gn; Gn = tsw;
         cur ^= 1;
         ++rounds;
+        last_big1 = max(last_big1, big_slot);
+        if (rounds - last_big1 >= ne - 1) { converged = 1; break; }
       }
-      const int any_rot = sFlag[0], big_rot = sFlag[1];
-      __syncthreads();
-      if (!any_rot || !big_rot) { converged = 1; ++sweeps; break; }
-      if (tid == 0) { sFlag[0] = 0; sFlag[1] = 0; }
-      kept2 = kept_scale(Gc);
+      if (!converged) kept2 = kept_scale(Gc);
     }
   } else {
     converged = 1;

@@ -2,15 +2,12 @@
 // the per-step wide kernel (f from the previous B, activation / loss derivative / metrics,
 // environment extension, partial bond gradient) and the slab reduction.
 //
-// v1 = plain FMA + LDS formulation, written for correctness and coalesced HBM access; the MFMA
-// formulation of the two GEMM-shaped parts replaces it where profiling says so.
+// The per-step kernels here are the CLASSIC launch sequence (batch kernel -> [reduction] -> update/SVD kernel); the default
+// path since round 2 is the pipelined single-launch step (wide_pipe_device.h + kernels_narrow.hip), which keeps these for
+// steps whose merged tensor does not fit one workgroup's LDS (large-tensor path) and for the standalone entry points.
 //
 // Layouts: features x[site][b_pad][D]; environments env[slot][m][b_pad] (bond-major, the batch is
 // the contiguous axis, so a wave reads 64 consecutive samples of one bond index); f [L][b_pad].
-#include <cstdlib>
-
-#include <string>
-
 #include "tnml_internal.h"
 #include "small_gemm_device.h"
 #include "act_device.h"
@@ -213,7 +210,9 @@ static size_t wide_lds_bytes(int hmax, int gmax, int L, int core_elems) {
 }
 
 // ------------------------------------------------------------------------------------------
-// The wide step kernel: one workgroup = kTS samples.
+// Last-resort batch kernel (plain FMA, operands streamed from global memory): one workgroup = kTS samples.  Taken only when a
+// tile's operands fit neither MFMA kernel's LDS budget (bond 64 with three labels: tests/test_true_shapes_gpu.py::
+// test_largest_matrix_side_of_the_large_path runs it).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWideThreads) void wide_step_kernel(WideParams p, int hmax, int gmax,
                                                                 int core_elems) {
@@ -894,42 +893,36 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(Wide
 #undef GLDS
 }
 
-static bool wide_use_mfma() {
-  static const int v = [] { const char *e = getenv("TNML_WIDE"); return (e && e[0] == 'v' && e[1] == '1') ? 0 : 1; }();
-  return v != 0;
-}
-
-bool launch_wide(const WideParams &p, int nblk, const PrepParams *prep, hipStream_t st) {
-  if (wide_use_mfma()) {
-    WideMfmaDims dm = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
-    size_t lds = wide_mfma_carve(nullptr, dm, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
-    static const bool force_tiled = [] { const char *e = getenv("TNML_WIDE"); return e && std::string(e) == "tiled"; }();
-    if (lds > 160 * 1024 || force_tiled) {
-      // operands of a tile exceed LDS (or the tiled kernel is forced for tests): stream the merged tensor in chunks
-      WideMfmaDims dt = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
-      const size_t ldst = wide_tiled_carve(nullptr, dt, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
-      if (ldst <= 160 * 1024 && p.L * (kTS / 16) <= 4 * (kMfmaThreads / 64)) {
-        hipLaunchKernelGGL(wide_step_mfma_tiled_kernel, dim3(nblk), dim3(kMfmaThreads), ldst, st, p);
-        return false;
-      }
+// false: the operands of a sample tile fit neither MFMA kernel's LDS budget (bond dimensions beyond what this build handles)
+bool launch_wide(const WideParams &p, int nblk, const PrepParams *prep, hipStream_t st, bool *prep_done) {
+  *prep_done = false;
+  WideMfmaDims dm = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
+  size_t lds = wide_mfma_carve(nullptr, dm, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
+  if (lds <= 160 * 1024) {
+    PrepParams q{};
+    int extra = 0;
+    if (prep) {
+      const size_t need = prep_slice_lds_bytes(prep->h, prep->g, prep->s, prep->L);
+      if (need <= 160 * 1024) { q = *prep; extra = kD * kD; if (need > lds) lds = need; }
     }
-    if (lds <= 160 * 1024) {
-      PrepParams q{};
-      int extra = 0;
-      if (prep) {
-        const size_t need = prep_slice_lds_bytes(prep->h, prep->g, prep->s, prep->L);
-        if (need <= 160 * 1024) { q = *prep; extra = kD * kD; if (need > lds) lds = need; }
-      }
-      hipLaunchKernelGGL(wide_step_mfma_kernel, dim3(nblk + extra), dim3(kMfmaThreads), lds, st, p, q, nblk);
-      return extra > 0;
-    }
+    hipLaunchKernelGGL(wide_step_mfma_kernel, dim3(nblk + extra), dim3(kMfmaThreads), lds, st, p, q, nblk);
+    *prep_done = extra > 0;
+    return true;
+  }
+  // operands of a tile exceed LDS: stream the merged tensor through it in chunks
+  WideMfmaDims dt = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
+  const size_t ldst = wide_tiled_carve(nullptr, dt, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
+  if (ldst <= 160 * 1024 && p.L * (kTS / 16) <= 4 * (kMfmaThreads / 64)) {
+    hipLaunchKernelGGL(wide_step_mfma_tiled_kernel, dim3(nblk), dim3(kMfmaThreads), ldst, st, p);
+    return true;
   }
   const int hmax = p.h > p.hp ? p.h : p.hp;
   const int gmax = p.g > p.gp ? p.g : p.gp;
   const int core_elems = p.do_ext ? p.ext_core.n_in * kD * p.ext_core.n_out : 0;
-  hipLaunchKernelGGL(wide_step_kernel, dim3(nblk), dim3(kWideThreads), wide_lds_bytes(hmax, gmax, p.L, core_elems),
-                     st, p, hmax, gmax, core_elems);
-  return false;
+  const size_t ldsv = wide_lds_bytes(hmax, gmax, p.L, core_elems);
+  if (ldsv > 160 * 1024) return false;
+  hipLaunchKernelGGL(wide_step_kernel, dim3(nblk), dim3(kWideThreads), ldsv, st, p, hmax, gmax, core_elems);
+  return true;
 }
 
 void launch_f_only(const WideParams &p, int nblk, hipStream_t st) {

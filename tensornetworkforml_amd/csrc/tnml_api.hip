@@ -65,7 +65,7 @@ struct tnml_ctx {
   bool check_launches = false;               // tnml_debug_enable bit 2: read the launch status back after every kernel launch
   int sync_interval = 0;                     // tnml_set_sync_interval: drain the stream every so many steps (0 = never)
   double svd_stop2 = kSvdStop2Default;
-  double chol_thr = getenv("TNML_CHOL_THR") ? atof(getenv("TNML_CHOL_THR")) : kCholThrDefault;   // 0 disables the step
+  double chol_thr = kCholThrDefault;         // off(G) / trace(G) above which the pivoted-Cholesky step runs (0 disables it)
   double trunc_thr = 0.999;                  // adaptive truncation threshold (tensor_svd's default argument)
   double prof_ms[4] = {0, 0, 0, 0};
   long long prof_n[4] = {0, 0, 0, 0};
@@ -76,6 +76,8 @@ struct tnml_ctx {
   size_t sweep_ev_used = 0;
   double sweep_ms = 0;
   long long sweep_launches = 0, step_launches = 0;
+  // tnml_get_counters: work since the last tnml_profile_reset, from the dimensions of every step actually run
+  double cnt_steps = 0, cnt_bytes = 0, cnt_flops = 0, cnt_fwd_bytes = 0, cnt_fwd = 0;
   // staged batches (tnml_stage_batch / tnml_select_batch): device-resident [b][N][D] inputs + labels
   static constexpr int kStageSlots = 8;
   float *stageX[kStageSlots] = {nullptr};
@@ -141,22 +143,7 @@ extern "C" int tnml_device_count(void) {
   return n;
 }
 
-extern "C" int tnml_trunc_rank(int policy, int left_dir, int p, int N, int ml, int D, int mr, int L, int M) {
-  // Network_class.py:894-910 (right sweep) and :931-945 (left sweep)
-  const int rows = left_dir ? D * ml * L : D * ml;
-  const int cols = left_dir ? D * mr : D * mr * L;
-  const int nS = std::min(rows, cols);
-  if (policy == TNML_TRUNC_FIXED || policy == TNML_TRUNC_ADAPTIVE) return std::min(M, nS);   // adaptive: the cap
-  const bool first = (p == 0), last = (p == N - 2);
-  if (!left_dir) {
-    if (first) return rows == nS ? nS : TNML_ERR_SHAPE;   // only Vh cut, U stays rows x rows
-    if (!last) return ml <= nS ? ml : TNML_ERR_SHAPE;     // m = left bond of the merged tensor
-    return cols == nS ? nS : TNML_ERR_SHAPE;              // only U cut, Vh stays cols x cols
-  }
-  if (last) return cols == nS ? nS : TNML_ERR_SHAPE;
-  if (!first) return ml <= nS ? ml : TNML_ERR_SHAPE;
-  return rows == nS ? nS : TNML_ERR_SHAPE;
-}
+#include "host_plan.inc"      // tnml_trunc_rank, canon_to_rel: pure host arithmetic, also built with sanitizers (make san)
 
 static int alloc_batch_buffers(tnml_ctx *c, int b_cap) {
   const int b_pad = (b_cap + 63) / 64 * 64;
@@ -578,6 +565,8 @@ static int run_chain(tnml_ctx *c, bool logmode) {
     c->prof_ms[0] += ms; c->prof_n[0]++;
   }
   if (!logmode) {
+    c->cnt_fwd += 1;
+    for (int i = 0; i < N - 1; ++i) c->cnt_fwd_bytes += 4.0 * c->b * (2.0 * c->bond[i] + D);      // environment in + out, features
     c->envs_valid_R = right_envs;
     c->envs_valid_L = !right_envs;
     c->f_current = true;
@@ -723,8 +712,7 @@ static int ensure_big(tnml_ctx *c) {
 
 // which path a step of these dimensions takes: 0 in-LDS, 1 large-tensor, <0 error already reported
 static int narrow_path(const tnml_ctx *c, int h, int g, int s, int L, int m) {
-  static const bool env_big = getenv("TNML_NARROW") && std::string(getenv("TNML_NARROW")) == "big";
-  const bool force_big = env_big || c->force_big;
+  const bool force_big = c->force_big;
   const int r = kD * h, cc = kD * g * L, nn = std::min(r, cc);
   const size_t lds = narrow_lds_bytes(h, g, s, L, m);
   if (!force_big && nn <= 64 && lds <= 160 * 1024) return 0;
@@ -933,7 +921,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     // single GPU + in-LDS path: the slab reduction rides in the narrow launch as helper workgroups (no separate
     // reduce kernel, no boundary) and the merge / L2 products ride in the wide launch (or, with the plain-FMA wide
     // kernel, in the narrow launch as well); TNML_NARROW_FUSED=0 turns all of that off
-    static const bool fuse_ok = !(getenv("TNML_NARROW_FUSED") && atoi(getenv("TNML_NARROW_FUSED")) == 0);
+    const bool fuse_ok = true;
     const bool prep_ok = fuse_ok && npath == 0 && mode == 0 && !Bdirect_dev;     // merge / L2 slices in the wide launch
     const bool fused = prep_ok && !c->comm;                                       // + slab reduction in the narrow launch
     NarrowParams n{};
@@ -1097,7 +1085,10 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       prep.lab = n.lab; prep.pl = n.pl; prep.Nh = n.Nh; prep.Ng = n.Ng; prep.h = h; prep.g = g; prep.s = s; prep.L = L;
       prep.l2_flag = n.l2_flag; prep.prepB = c->prepB; prep.prepG = c->prepG;
       prof_begin(c);
-      n.prep_ready = launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream) ? 1 : 0;
+      bool prep_done = false;
+      if (!launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream, &prep_done))
+        return fail(TNML_ERR_ARG, "step at sites (%d,%d): a 32-sample tile of this bond dimension does not fit the batch kernels' LDS", p, p + 1);
+      n.prep_ready = prep_done ? 1 : 0;
       if (n.fused) n.wait_count = n.nred + (n.prep_ready ? 0 : kD * kD);
       prof_end(c, 1);
       // ---- reduce (+ all-reduce over the batch shards) -----------------------------------------
@@ -1111,10 +1102,6 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       { int rc = run_narrow(c, n, npath); if (rc) return rc; }
       prof_end(c, 3);
       c->sweep_launches += (fused ? 2 : 3) + (npath == 1 ? 11 : 0);
-      {   // diagnostic: TNML_EXTRA_LAUNCHES=k adds k trivial dependent launches per step (prices a boundary)
-        static const int extra = getenv("TNML_EXTRA_LAUNCHES") ? atoi(getenv("TNML_EXTRA_LAUNCHES")) : 0;
-        for (int x = 0; x < extra; ++x) launch_scale(c->scal, 1, 1.0f, c->stream);
-      }
       c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
       if (mode == 1) {
         // the behind environment list grew (as update_B does, Network_class.py:637-652); nothing else changes
@@ -1137,6 +1124,13 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     c->l_pos = sa;
     c->lab_cur ^= 1;
     c->prev_h = h; c->prev_g = g; c->prev_p = p; c->prev_left_dir = left_dir;
+    {   // algorithmic work of this step (SURVEY.md 8.4 with the step's own bond dimensions): environments read / written,
+      // features of three sites, f in and out, labels; gradient + f products and the environment extension
+      const double bb = (double)c->b;
+      c->cnt_steps += 1;
+      c->cnt_bytes += 4.0 * bb * (2.0 * h + g + 3.0 * D + 2.0 * L + 1.0);
+      c->cnt_flops += 4.0 * bb * D * D * h * g * L + 2.0 * bb * D * h * h;
+    }
     c->Bnew_valid = true;
     c->f_current = pipe;          // the batch-side workgroups of a pipelined launch stored f of this step already
     c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
@@ -1181,16 +1175,6 @@ extern "C" int tnml_sweep(tnml_ctx *c, int left_dir, int n_steps, int first_of_s
                           float *f_out) {
   return sweep_impl(c, left_dir, n_steps, first_of_sweep, lr, weight_dec, l2_flag, act_fn, loss_fn, T, trunc_policy,
                     metrics_out, f_out, 0, nullptr);
-}
-
-// canonical (a, d, d', c, l) <-> sweep-relative (h, dk, dk1, g, l) layout of a merged tensor on sites (p, p+1)
-template <class Tsrc, class Tdst>
-static void canon_to_rel(const Tsrc *src, Tdst *dst, int left_dir, int ml, int mr, int D, int L) {
-  if (!left_dir) { for (size_t e = 0; e < (size_t)ml * D * D * mr * L; ++e) dst[e] = (Tdst)src[e]; return; }
-  const int h = mr, g = ml;      // behind = right, ahead = left
-  for (int h_ = 0; h_ < h; ++h_) for (int dk = 0; dk < D; ++dk) for (int dk1 = 0; dk1 < D; ++dk1)
-    for (int g_ = 0; g_ < g; ++g_) for (int l = 0; l < L; ++l)
-      dst[((((size_t)h_ * D + dk) * D + dk1) * g + g_) * L + l] = (Tdst)src[((((size_t)g_ * D + dk1) * D + dk) * h + h_) * L + l];
 }
 
 static int norm_envs_for_label_site(tnml_ctx *c) {
@@ -1476,6 +1460,14 @@ extern "C" int tnml_profile_get(tnml_ctx *c, int which, double *ms, long long *l
   if (launches) *launches = c->prof_n[which];
   return TNML_OK;
 }
+extern "C" int tnml_get_counters(tnml_ctx *c, double *out8) {
+  if (!c || !out8) return fail(TNML_ERR_ARG, "NULL argument");
+  out8[0] = c->cnt_steps; out8[1] = c->cnt_bytes; out8[2] = c->cnt_flops;
+  out8[3] = c->cnt_fwd; out8[4] = c->cnt_fwd_bytes;
+  out8[5] = (double)c->sweep_launches; out8[6] = (double)c->step_launches; out8[7] = c->sweep_ms;
+  return TNML_OK;
+}
+
 extern "C" int tnml_svd_stats(tnml_ctx *c, int reset, double *out3) {
   if (!c || !out3) return fail(TNML_ERR_ARG, "NULL argument");
   HIP_TRY(hipSetDevice(c->device));
@@ -1491,5 +1483,6 @@ extern "C" int tnml_profile_reset(tnml_ctx *c) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   for (int i = 0; i < 4; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
   c->sweep_ms = 0; c->sweep_launches = 0; c->step_launches = 0; c->sweep_ev_used = 0;
+  c->cnt_steps = c->cnt_bytes = c->cnt_flops = c->cnt_fwd_bytes = c->cnt_fwd = 0;
   return TNML_OK;
 }

@@ -142,8 +142,9 @@ struct PrepParams {
   double *prepG;
 };
 
-// returns true when the launch carried the D*D slice workgroups that fill prep.prepB / prep.prepG (MFMA kernel only)
-bool launch_wide(const WideParams &p, int nblk, const PrepParams *prep, hipStream_t st);
+// false: no kernel of this build fits the tile's operands into LDS.  *prep_done: the launch carried the D*D slice workgroups
+// that fill prep.prepB / prep.prepG
+bool launch_wide(const WideParams &p, int nblk, const PrepParams *prep, hipStream_t st, bool *prep_done);
 void launch_f_only(const WideParams &p, int nblk, hipStream_t st);
 void launch_reduce(const float *slabs, int nblk, int slab_stride, int n, float *red, hipStream_t st);
 void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st);   // grid = p.fused ? 1 + p.wait_count : 1

@@ -390,3 +390,27 @@ def test_batch_larger_than_the_capacity_given_at_creation():
         _, f_d = ctx.sweep(left, N - 1, True, 1e-2, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
         assert relerr(f_d, f_o) < 1e-3, b
     ctx.close()
+
+
+def test_counters_and_classic_sequence_agree_with_the_pipelined_step():
+    """tnml_get_counters accounts for the steps that ran; the classic launch sequence (tnml_set_step_pipeline(0)) and the
+    default single-launch step give the same sweep to float32 rounding."""
+    d = gu.load('traj_fixed_N16_script')
+    N, M, L, D = int(d['N']), int(d['M']), int(d['L']), int(d['D'])
+    kw = _kw(d)
+    outs = []
+    for pipe in (True, False):
+        ctx = make_ctx(N, D, L, M, gu.indexed(d, 'init_core', N), 0, d['X'], d['y'])
+        ctx.set_step_pipeline(pipe)
+        ctx.profile_reset()
+        ctx.forward()
+        met, f = ctx.sweep(False, N - 1, True, kw['lr'], kw['weight_dec'], kw['L2_flag'], kw['act_fn'], kw['loss_fn'], kw['T'], kw['trunc'])
+        cnt = ctx.counters()
+        assert cnt['sweep_steps'] == N - 1 and cnt['forwards'] == 1
+        assert cnt['algorithmic_bytes'] > 0 and cnt['algorithmic_flops'] > 0 and cnt['forward_bytes'] > 0
+        assert cnt['pipelined_steps'] == (N if pipe else 0)          # N - 1 steps + the launch that starts the sweep
+        assert cnt['launches'] >= N - 1
+        outs.append((met, f))
+        ctx.close()
+    assert relerr(outs[0][1], outs[1][1]) < 1e-4
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-5

@@ -176,3 +176,16 @@ def test_random_init_matches_reference_draw_order():
     ref = mo.random_cores(5, 3, 2, 2, scale=1.7)
     for a, b in zip(mine, ref):
         np.testing.assert_array_equal(a, b)
+
+
+def test_host_arithmetic_under_sanitizers():
+    """csrc/Makefile target `san`: the library's pure host arithmetic (truncation ranks, layout permutations: host_plan.inc,
+    the same text tnml_api.hip includes) compiled with -fsanitize=address,undefined and run over a grid of shapes."""
+    import shutil
+    import subprocess
+    if shutil.which('g++') is None:
+        pytest.skip('no g++')
+    csrc = os.path.join(ROOT, 'tensornetworkforml_amd', 'csrc')
+    out = subprocess.run(['make', '-C', csrc, 'san'], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'sanitizer test ok' in out.stdout
