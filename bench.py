@@ -197,6 +197,16 @@ def main():
     hp = dict(lr=1e-3, weight_dec=1e-3, L2_flag=not args.no_l2, act_fn='softmax', loss_fn='full_cross_ent', T=0.1,
               trunc=args.policy)
     counter = [0]
+    # device time of EVERY sweep of this process (for comparison with a rocprofv3 --kernel-trace --stats summary of the same
+    # command, whose per-kernel average runs over all launches, not only the timed passes)
+    whole = {'ms': 0.0, 'launches': 0}
+
+    def drain_whole():
+        ms, _ = ctx.profile_get(4)
+        _, nl = ctx.profile_get(5)
+        whole['ms'] += ms
+        whole['launches'] += nl
+        ctx.profile_reset()
 
     def one_pass(want=False, rotate=True):
         if rotate and nb > 1:
@@ -216,7 +226,7 @@ def main():
     def timed(n_pass, **kw):
         barrier()
         ctx.svd_stats(reset=True)
-        ctx.profile_reset()
+        drain_whole()
         ctx.profile_enable(2)      # one event pair per sweep call on the library's stream; nothing waits inside
         t0 = time.perf_counter()
         for _ in range(n_pass):
@@ -228,11 +238,13 @@ def main():
         sweep_ms, n_launch = ctx.profile_get(4)
         cnt = ctx.counters()
         _, n_steps_pipe = ctx.profile_get(5)
-        ctx.profile_enable(0)
+        drain_whole()
         sw_tot, n_svd, rounds_tot = ctx.svd_stats(reset=True)
         return dict(dt=dt, sweep_ms=sweep_ms, launches=n_launch, pipe_steps=n_steps_pipe, counters=cnt,
                     sweeps_per_svd=sw_tot / max(n_svd, 1), rounds_per_svd=rounds_tot / max(n_svd, 1))
 
+    ctx.profile_reset()
+    ctx.profile_enable(2)
     for _ in range(args.warmup):
         one_pass()
     main_run = timed(args.steps)
@@ -306,7 +318,9 @@ def main():
     # pre-gradient of step k+1), so it is the dominant kernel and its average duration is the device time of the timed
     # sweeps (HIP events on the library's stream, first to last launch of each sweep) / launches.  Classic sequence and the
     # large-tensor path (c5): several kernels per step; the figure is then the whole step per launch group.
-    step_launches = main_run['pipe_steps'] if main_run['pipe_steps'] else sweep_steps
+    # (c5: only the steps next to the chain ends fit the single-launch kernel; the figure there is per sweep step)
+    all_pipe = main_run['pipe_steps'] >= sweep_steps
+    step_launches = main_run['pipe_steps'] if all_pipe else sweep_steps
     step_us = 1e3 * main_run['sweep_ms'] / max(step_launches, 1)
     if args.config == 'c5':
         fl = flops_per_step(b, M, D, L)
@@ -316,7 +330,7 @@ def main():
                            'algorithmic_flops_per_step': fl, 'algorithmic_bytes_per_step': bstep, 'step_avg_us_hip_events': step_us}
     else:
         ach = bstep / (step_us * 1e-6) / 1e9
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'step_pipe_kernel' if main_run['pipe_steps'] else 'wide_step_mfma_kernel + narrow_step_kernel',
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'step_pipe_kernel' if all_pipe else 'wide_step_mfma_kernel + narrow_step_kernel',
                            'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
                            'algorithmic_bytes_per_launch': bstep, 'kernel_avg_us_hip_events': step_us, 'launches_timed': step_launches,
                            'note': 'one launch = one whole sweep step; the step is bound by the sequential SVD of its merged tensor '
@@ -332,11 +346,11 @@ def main():
 
     if rank == 0 and not args.no_kernel_profile:
         # per-kernel device time with HIP events around every launch (two more passes; synchronises after each launch)
-        ctx.profile_reset()
+        drain_whole()
         ctx.profile_enable(1)
         one_pass()
         one_pass()
-        ctx.profile_enable(0)
+        ctx.profile_enable(2)
         names = ['env_chain_kernel', 'batch-side kernel (classic wide kernel / prologue of a pipelined sweep)', 'reduce_slabs_kernel',
                  'step kernel (step_pipe_kernel, or the classic narrow kernel / large-tensor chain)']
         kern = {}
@@ -414,6 +428,10 @@ def main():
                 'forms': rf,
                 'gpu_over_B3': steps_per_s / rf['B3_fixed_bond_L2']['steps_per_s'],
                 'gpu_over_B1': steps_per_s / rf['B1_reference_truncation_L2']['steps_per_s']}
+    drain_whole()
+    if 'roofline' in out and whole['launches'] and all_pipe:
+        out['roofline']['step_kernel_avg_us_hip_events_whole_run'] = 1e3 * whole['ms'] / whole['launches']
+        out['roofline']['step_kernel_launches_whole_run'] = whole['launches']
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

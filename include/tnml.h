@@ -141,7 +141,7 @@ int tnml_sweep(tnml_ctx *ctx, int left_dir, int n_steps, int first_of_sweep, flo
  *                   l_pos are left untouched; metrics2 = (accuracy, MAE) or NULL.
  *   tnml_l2_term    Network.compute_L2_reg (:966-1179): loss = wd <B, Ln.B.Rn>, grad = 2 wd Ln.B.Rn.
  *   tnml_svd_split  Network.tensor_svd (:839-962): U sqrt(S) [rows][m] and sqrt(S) Vh [m][cols] of a
- *                   rows x cols matrix (both multiples of D, min <= 64), sigma[min(rows, cols)] or NULL. */
+ *                   rows x cols matrix (both multiples of D, min <= 128), sigma[min(rows, cols)] or NULL. */
 int tnml_update_B(tnml_ctx *ctx, const float *B_canon, int left_dir, float lr, float weight_dec, int l2_flag,
                   int act_fn, int loss_fn, float T, double *Bnew_canon, size_t capacity, float *metrics2);
 int tnml_l2_term(tnml_ctx *ctx, const float *B_canon, int left_dir, float weight_dec, double *loss,
@@ -176,6 +176,9 @@ int tnml_set_sync_interval(tnml_ctx *ctx, int n_steps);
 /* The batch-independent part of a step (update_B's tail, compute_L2_reg, tensor_svd) runs in one
  * workgroup's LDS when the merged tensor fits (min(rows, cols) <= 64 and <= 160 KB of LDS: bond <= 32 at
  * two labels) and through HBM-resident kernels otherwise (min(rows, cols) <= 128: bond 50 with ten labels).
+ * LIMIT: the Jacobi kernels take a short side of at most 128, i.e. bond dimension M <= 64 at D = 2; tnml_sweep
+ * returns TNML_ERR_ARG at the first step beyond it (the reference itself has no such limit; its largest published
+ * bond is 50).
  * force_large = 1 sends every step down the second path (tests, diagnostics); 0 restores the automatic
  * choice. */
 int tnml_set_narrow_path(tnml_ctx *ctx, int force_large);
