@@ -345,7 +345,7 @@ class Context:
         _chk(lib().tnml_debug_enable(self._h, int(on)))
 
     def step_debug(self, what):
-        cap = 4 * max(self.M, self.D * self.L) ** 2 * self.D * self.D * self.L + 64
+        cap = max(4 * max(self.M, self.D * self.L) ** 2 * self.D * self.D * self.L + 64, 512)
         out = np.empty(cap, dtype=np.float64)
         n = C.c_size_t()
         _chk(lib().tnml_get_step_debug(self._h, DBG[what], _ptr(out, C.c_double), out.size, C.byref(n)))

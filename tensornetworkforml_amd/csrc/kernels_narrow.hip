@@ -41,17 +41,25 @@ __device__ inline double wave_sum_f64(double v) {
   return (r0 + r1) + (r2 + r3);
 }
 
-// block-wide sum of up to 3 doubles; result valid (and bitwise identical) in every thread.  scratch: >= 3*16 doubles.
+// block-wide sum of up to 3 doubles; result valid (and bitwise identical) in every thread.  One barrier: wave totals by DPP,
+// 16 partials per value through LDS, then the same 4-step xor-butterfly over the 16 partials in every 16-lane row of every
+// wave (fp addition is commutative: every lane ends with the same bits).  scratch: 128 doubles; BUF selects one of two
+// 48-double areas -- a call needs no barrier of its own before or after as long as two calls that share a BUF are
+// separated by another barrier of the workgroup.
+template <int BUF>
 __device__ inline void block_sum3(double &a, double &b, double &c, double *scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double *s = scratch + BUF * 64;
   a = wave_sum_f64(a); b = wave_sum_f64(b); c = wave_sum_f64(c);
+  if (lane == 0) { s[wave] = a; s[16 + wave] = b; s[32 + wave] = c; }
   lds_barrier();
-  if (lane == 0) { scratch[wave] = a; scratch[16 + wave] = b; scratch[32 + wave] = c; }
-  lds_barrier();
-  double ta = 0.0, tb = 0.0, tc = 0.0;
-  for (int w = 0; w < nw; ++w) { ta += scratch[w]; tb += scratch[16 + w]; tc += scratch[32 + w]; }   // wave order, broadcast reads
+  const int w = lane & 15;
+  double ta = w < nw ? s[w] : 0.0, tb = w < nw ? s[16 + w] : 0.0, tc = w < nw ? s[32 + w] : 0.0;
+  ta += dpp_f64<0xB1>(ta); tb += dpp_f64<0xB1>(tb); tc += dpp_f64<0xB1>(tc);
+  ta += dpp_f64<0x4E>(ta); tb += dpp_f64<0x4E>(tb); tc += dpp_f64<0x4E>(tc);
+  ta += dpp_f64<0x141>(ta); tb += dpp_f64<0x141>(tb); tc += dpp_f64<0x141>(tc);
+  ta += dpp_f64<0x140>(ta); tb += dpp_f64<0x140>(tb); tc += dpp_f64<0x140>(tc);
   a = ta; b = tb; c = tc;
-  lds_barrier();
 }
 
 struct NarrowCarve {
@@ -83,7 +91,7 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
   k.dNh = d; d += ((size_t)h * h + 1) & ~(size_t)1;
   k.dNg = d; d += ((size_t)g * g + 1) & ~(size_t)1;
   k.dLam = d; d += ne;
-  k.dRed = d; d += 64;
+  k.dRed = d; d += 128;        // block_sum3: two areas of 48 at 0 and 64; slots 60..62: single values
   k.dT2 = d; d += (size_t)h * D * m;
   k.dCS = d; d += 4 * ne;                   // (c, s, t, -) per pair, two rounds in flight
   k.dSq = d; d += 2 * ne;                   // sigma^(1/2) and sigma^(-1/2) of the kept columns
@@ -194,12 +202,17 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   for (int i = 0; i < 24; ++i) t_y[i] = 0;
 #define XSTAMP(i) if (p.stamps && tid == 0) t_x[i] = __builtin_amdgcn_s_memtime()
 #define YSTAMP(i) if (p.stamps && tid == 0) t_y[i] = __builtin_amdgcn_s_memtime()
+  // per-wave probe points (lane 0 of every wave; absolute shader cycles, the host subtracts wave 0's point 0)
+  unsigned long long t_w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define WPROBE(i) if (p.stamps && (tid & 63) == 0) t_w[i] = __builtin_amdgcn_s_memtime()
 #else
 #define XSTAMP(i)
 #define YSTAMP(i)
+#define WPROBE(i)
 #endif
 #define TNML_STAMP(i) if (p.stamps && tid == 0) t_p[i] = __builtin_amdgcn_s_memtime()
   if (p.stamps && tid == 0) { t_c0 = __builtin_amdgcn_s_memtime(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
+  WPROBE(0);
   // ---- pipelined step: raw gradient dB[h_, rest] = sum_i' A_{k-1}[i', h_] Z_k[i', rest] (wide_pipe_device.h); both operands
   // were completed by the previous launch, so this runs before anything of this launch is waited for
   const int RWz = kD * kD * p.g * p.L;
@@ -256,11 +269,15 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       if (p.tail_prep && e < g * D * p.g2) k.sPl2[e] = rpl[u];
     }
     YSTAMP(1);
+    WPROBE(1);
     lds_barrier();
     YSTAMP(2);
     if (!p.z_first)
       mm_lds_f32(h, RWz, zr, sZc, 1, h, sZ, RWz, 1, [&](int i, int j, float v) { k.dT[i * RWz + j] = (double)v; });
     YSTAMP(3);
+#ifndef TNML_EXP_GRAM_TWICE
+    WPROBE(2);
+#endif
     if (!p.prep_ready) {
       // merged tensor and L2 term from the slice workgroups of THIS launch: wait for their arrivals, then agent-scope loads,
       // all in flight together
@@ -292,6 +309,9 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       }
     }
     YSTAMP(4);
+#ifndef TNML_EXP_GRAM_TWICE
+    WPROBE(3);
+#endif
   } else if (p.pipe && !p.z_first) {
     const float *zc = p.zcore.base;
     const int zs_in = p.zcore.s_in, zs_d = p.zcore.s_d, zs_out = p.zcore.s_out;
@@ -433,8 +453,12 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     sumD += fabs(dv);
   }
   XSTAMP(0);
-  block_sum3(sumB, sumD, l2, k.dRed);
+#ifndef TNML_EXP_GRAM_TWICE
+  WPROBE(4);
+#endif
+  block_sum3<0>(sumB, sumD, l2, k.dRed);
   XSTAMP(1);
+  WPROBE(5);
 
   // ---- phase 5: clip + update (Network_class.py:755-761) ----------------------------------------
   double factor = (double)p.lr;
@@ -460,6 +484,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     }
   }
   XSTAMP(2);
+  WPROBE(6);
   lds_barrier();   // dT/dG are dead from here on; Z aliases them
   // B_new is complete in memory: the batch-side workgroups of this launch may form f and the next pre-gradient from it
   // while this workgroup goes on to the SVD
@@ -475,6 +500,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   }
 
   TNML_STAMP(3);
+  WPROBE(7);
   // ---- phase 6: Gram matrix in float64 (padded to ne x ne with a zero row/column), V = I ----------
   //   W(x, kk) = short_rows ? Bm[kk][x] : Bm[x][kk]   with Bm = B_new as (r x c) row-major
   double *G0 = k.Z, *G1 = k.Z + ne * ne, *V0 = k.Z + 2 * ne * ne;
@@ -483,6 +509,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // the (tile, slice) items dealt round-robin to all 16 waves; slice partials land in the four ne x ne buffers of
   // the Jacobi region and are summed in slice order (deterministic).
   constexpr int kGramSplit = 4;
+  double g_tr = 0.0, g_dg2 = 0.0, g_off2 = 0.0;
   {
     double *P0 = G0, *P1 = G1, *P2 = V0, *P3 = k.Z + 3 * ne * ne;
     const int lane = tid & 63, wave = tid >> 6, rr = lane & 15, qq = lane >> 4;
@@ -490,59 +517,82 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     const int kchunk = ((len + kGramSplit - 1) / kGramSplit + 3) & ~3;       // multiple of the MFMA k = 4
     // (tile, slice) items dealt round-robin to the waves: nested counters, no integer division (a per-lane division costs
     // 134 cycles, a wave-uniform one ~40 scalar instructions: tools/ubench/prims.hip)
-    int slot = 0;
-    for (int ti = 0; ti < tm; ++ti)
-     for (int tj = ti; tj < tm; ++tj)
-      for (int ks = 0; ks < kGramSplit; ++ks) {
-      const bool mine = slot == wave;
-      slot = slot + 1 == (NT >> 6) ? 0 : slot + 1;
-      if (!mine) continue;
+#ifdef TNML_EXP_GRAM_TWICE      // instruction-cache experiment: the same code a second time (probe points 2/3 = second pass)
+#pragma nounroll
+    for (int gram_rep = 0; gram_rep < 2; ++gram_rep) {
+    if (gram_rep == 1) { WPROBE(2); }
+#endif
+    // this wave's (tile, slice) items, decoded from a wave-uniform index with scalar instructions only (the wave index is
+    // made uniform for the compiler by v_readfirstlane); W(x, kk) = Wb[x * rs + kk * cs]
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const float *Wb = short_rows ? k.fBp : k.fB;
+    const int rs = short_rows ? c + 1 : 1, cs = short_rows ? 1 : c;
+    const int nitems = ((tm * (tm + 1)) >> 1) * kGramSplit;
+    for (int item = wave_s; item < nitems; item += NT >> 6) {
+      const int ks = item & (kGramSplit - 1);
+      int t = item >> 2, ti = 0, rowlen = tm;              // kGramSplit == 4
+      while (t >= rowlen) { t -= rowlen; ++ti; --rowlen; }
+      const int tj = ti + t;
       const int i0 = ti << 4, j0 = tj << 4;
-      const int ia = min(i0 + rr, n - 1), jb = min(j0 + rr, n - 1);
       const bool va = i0 + rr < n, vb = j0 + rr < n;
+      const float *pa = Wb + min(i0 + rr, n - 1) * rs, *pb = Wb + min(j0 + rr, n - 1) * rs;
       const int k_lo = ks * kchunk, k_hi = min(len, k_lo + kchunk);
       dvec4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-      for (int k0 = k_lo; k0 < k_hi; k0 += 8) {
-        double av[2], bv[2];
+      for (int k0 = k_lo; k0 < k_hi; k0 += 16) {           // up to four k-steps per trip, all LDS reads issued first
+        float fa[4], fb[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int kk = k0 + 4 * u + qq;
-          const bool vk = kk < k_hi;
-          const int kc = vk ? kk : k_hi - 1;
-          // rows of the padded copy (stride c + 1) keep the 16 lanes of an operand on 16 different banks
-          const float fa = short_rows ? k.fBp[ia * (c + 1) + kc] : k.fB[kc * c + ia];
-          const float fb = short_rows ? k.fBp[jb * (c + 1) + kc] : k.fB[kc * c + jb];
-          av[u] = (va && vk) ? (double)fa : 0.0;
-          bv[u] = (vb && vk) ? (double)fb : 0.0;
+        for (int u = 0; u < 4; ++u) {
+          const int kc = min(k0 + 4 * u + qq, k_hi - 1) * cs;
+          fa[u] = pa[kc];
+          fb[u] = pb[kc];
         }
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
-        if (k0 + 4 < k_hi) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool vk = k0 + 4 * u + qq < k_hi;
+          const double av = (va && vk) ? (double)fa[u] : 0.0, bv = (vb && vk) ? (double)fb[u] : 0.0;
+          if (k0 + 4 * u < k_hi) {
+            if (u & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc0, 0, 0, 0);
+          }
+        }
       }
       const dvec4 acc = acc0 + acc1;
       const int j = j0 + rr;
-      double *Pk = ks == 0 ? P0 : (ks == 1 ? P1 : (ks == 2 ? P2 : P3));
+      double *Pk = P0 + (size_t)ks * ne * ne;              // the four ne x ne buffers are contiguous
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int i = i0 + qq + 4 * reg;
         if (i < ne && j < ne) Pk[i * ne + j] = (i < n && j < n) ? acc[reg] : 0.0;     // padding row / column = 0
       }
     }
+#ifdef TNML_EXP_GRAM_TWICE
+    if (gram_rep == 0) { WPROBE(8); lds_barrier(); WPROBE(9); } else { WPROBE(3); }
+    }
+#else
+    WPROBE(8);
+#endif
     lds_barrier();
     XSTAMP(3);
-    // sum of the slices, in slice order, mirrored into the lower triangle (exact symmetry); tiles below the diagonal were
-    // never written.  Rows over waves, columns over lanes: no division.
+#ifdef TNML_EXP_GRAM_TWICE
+    WPROBE(4);
+#else
+    WPROBE(9);
+#endif
+    // sum of the slices, in slice order, written to both triangles (exact symmetry; tiles below the diagonal were never
+    // written, and inside a diagonal tile only i <= j is read).  Rows over waves, columns over lanes: no division.  The
+    // same pass collects trace, sum of squared diagonal and of squared off-diagonal entries.
     for (int i = tid >> 6; i < ne; i += NT >> 6)
       for (int j = tid & 63; j < ne; j += 64)
-        if ((i >> 4) <= (j >> 4)) {
+        if (i <= j) {
           const int e = i * ne + j;
           const double v = ((P0[e] + P1[e]) + P2[e]) + P3[e];
-          if (i <= j) P0[e] = v;                                  // P0 == G0: in place
+          P0[e] = v;                                              // P0 == G0: in place
+          if (i < j) { G0[j * ne + i] = v; g_off2 += 2.0 * v * v; }
+          else { g_tr += v; g_dg2 += v * v; }
         }
-    lds_barrier();
-    for (int i = tid >> 6; i < ne; i += NT >> 6)
-      for (int j = tid & 63; j < i && j < ne; j += 64) G0[i * ne + j] = G0[j * ne + i];
   }
   XSTAMP(4);
+  WPROBE(10);
   // Tournament in POSITION space: the pairs of a round are always the positions (2k, 2k+1); after
   // the rotations every row/column moves to position pi(pos) of the next round (circle method:
   // position 0 fixed, top row shifts right, bottom row shifts left).  The move is free: the updated
@@ -556,31 +606,17 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     k.sPi[pos] = nxt;
     k.sPiInv[nxt] = pos;
   }
-  // SIMD of every wave (HW_REG_HW_ID bits 5:4): the Jacobi iteration keeps the SIMD of the parameter wave (wave 0) free of
-  // working waves -- its dependent chain of ~30 instructions sets the length of a round, and co-resident waves that issue
-  // float64 instructions of their own delay every link of it (round-1 timing experiment: parameters alone 740 cycles per
-  // round, next to the other roles 1130)
-  if ((tid & 63) == 0) k.sWave[tid >> 6] = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
-  lds_barrier();
   TNML_STAMP(4);
-  // scale G to trace ~ 1 by an exact power of two (undone on the eigenvalues in phase 8)
-  double tr = 0.0;                                        // n <= 64: one diagonal entry per lane, same tree in every wave
-  {
-    const int ln = tid & 63;
-    tr = ln < n ? G0[ln * ne + ln] : 0.0;
-    for (int off = 32; off > 0; off >>= 1) tr += __shfl_xor(tr, off);
-  }
+  WPROBE(11);
+  // scale G to trace ~ 1 by an exact power of two (undone on the eigenvalues in phase 8); the statistics of the summation
+  // pass decide about the Cholesky step (a ratio: the scale drops out)
+  block_sum3<1>(g_tr, g_dg2, g_off2, k.dRed);              // its barrier also publishes the summed G and the tables
+  const double tr = g_tr, off2 = g_off2;
   const int sc_exp = (tr > 0.0 && isfinite(tr)) ? __builtin_amdgcn_frexp_exp(tr) : 0;
+  const bool chol_possible = p.chol_thr > 0.0 && n > 4;   // tiny matrices (chain ends, reference policy): never worth it
+  for (int i = tid >> 6; i < ne; i += NT >> 6)
+    for (int j = tid & 63; j < ne; j += 64) G0[i * ne + j] = __builtin_amdgcn_ldexp(G0[i * ne + j], -sc_exp);
   lds_barrier();
-  double off2 = 0.0, dg2 = 0.0, dummy = 0.0;
-  const bool chol_possible = p.chol_thr > 0.0 && n > 4;   // tiny matrices (chain ends, reference policy): not worth a reduction
-  for (int e = tid; e < ne * ne; e += NT) {
-    const double v = __builtin_amdgcn_ldexp(G0[e], -sc_exp);
-    G0[e] = v;
-    if (e / ne == e % ne) dg2 += v * v; else off2 += v * v;
-  }
-  if (chol_possible) block_sum3(off2, dg2, dummy, k.dRed);
-  else lds_barrier();
 
   // ---- phase 6b: one pivoted-Cholesky step when G is far from diagonal ------------------------------------------
   // G = L L^T (diagonal pivoting), G' = L^T L has the same eigenvalues and is graded: the Jacobi iteration then needs
@@ -590,12 +626,11 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // of L is stored against the ORIGINAL row index (Lm[k][i] = L[i][k]), so G = L L^T and G' = L^T L hold as plain
   // products.
   double *Lm = k.Z + 3 * ne * ne;                          // free once the Gram partials are summed
-  const double trs = __builtin_amdgcn_ldexp(tr, -sc_exp);
   // threshold: measured break-even of the step against the sweeps it saves -- 0.22 for n >= 32 (C3: 8.1 k vs 7.8 k
   // steps/s, cold start +8 %), 0.35 for smaller matrices whose sweeps are cheaper (C2, n = 20: 0.22 costs 17 %, 0.35 is
   // neutral in the steady state and +2 % cold)
   const double cthr = n >= 32 ? p.chol_thr : fmax(p.chol_thr, kCholThrSmall);
-  const bool use_chol = chol_possible && off2 > cthr * cthr * trs * trs;
+  const bool use_chol = chol_possible && off2 > cthr * cthr * tr * tr;
   XSTAMP(5);
   if (use_chol) {
     for (int e = tid; e < ne * ne; e += NT) Lm[e] = 0.0;
@@ -696,21 +731,9 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // one block per lane when the V and G waves then still fit the workgroup (n <= 40: 7 + 4 of 15), two otherwise
   const int vr = ((np + gpw - 1) / gpw + (np * (np + 1) / 2 + 127) / 128 <= (NT >> 6) - 1) ? 1 : 2;
   const int NVW = (np + vr * gpw - 1) / (vr * gpw);      // V waves
-  // worker waves = the waves that do not share wave 0's SIMD, numbered densely (wrank); if the placement leaves too few
-  // of them (never observed: 16 waves spread 4 per SIMD), every wave but wave 0 works as before
-  int wrank = -1, nwork = 0;
-  {
-    const int mywave = tid >> 6, simd0 = k.sWave[0];
-    for (int w = 1; w < (NT >> 6); ++w) {
-      const bool shares = k.sWave[w] == simd0;
-      if (w == mywave && !shares) wrank = nwork;
-      nwork += shares ? 0 : 1;
-    }
-    const int nGw = (np * (np + 1) / 2 + 127) / 128;       // G waves needed at two items per thread
-    // (measured, round 2: once the parameter chain runs in float32 the round is bound by the float64 issue rate of the
-    // working waves, and giving them all four SIMDs is worth more than keeping the parameter wave's SIMD free)
-    if (true || nwork < NVW + nGw) { nwork = (NT >> 6) - 1; wrank = mywave - 1; }
-  }
+  // worker waves = every wave but wave 0 (the parameter wave).  (Measured, round 2: once the parameter chain runs in float32
+  // the round is bound by the float64 issue rate of the working waves; keeping wave 0's SIMD free of them does not pay.)
+  const int nwork = (NT >> 6) - 1, wrank = (tid >> 6) - 1;
   const int NW = (nwork - NVW) * 64;                     // threads that own G items
   const int gtid = (wrank - NVW) * 64 + (tid & 63);      // index among them (negative: not a G wave)
   const int vlane = tid & 63, vgrp = vlane / np, vQ = vlane - vgrp * np;
@@ -1126,6 +1149,10 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     p.stamps[6] = (double)(t_c2b - t_c2); p.stamps[7] = (double)(t_c2c - t_c2b); p.stamps[8] = (double)(t_c3 - t_c2c);
   }
 
+#ifdef TNML_EXP_FINE_STAMPS
+  if (p.stamps && (tid & 63) == 0)
+    for (int i = 0; i < 12; ++i) p.stamps[115 + (tid >> 6) * 12 + i] = (double)(t_w[i] & ((1ull << 44) - 1));
+#endif
   // ---- phase 11: metrics of this step (var_hist, Network_class.py:739-750) --------------------------
   if (tid == 0 && p.metrics) {
     const double cnt = (double)ldtail(3);

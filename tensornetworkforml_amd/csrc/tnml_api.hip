@@ -230,7 +230,7 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   c->metrics_cap = N;
   HIP_TRY(hipMalloc(&c->metrics, (size_t)c->metrics_cap * 2 * sizeof(float)));
   HIP_TRY(hipMalloc(&c->scal, 64 * sizeof(float)));
-  c->dbg_elems = 4 * c->bmax + kDbgSigma + 128;   // 4 tensors, sigma[kDbgSigma], 5 scalars, stamps
+  c->dbg_elems = 4 * c->bmax + kDbgSigma + kDbgScalars + 8;   // 4 tensors, sigma[kDbgSigma], 5 scalars, stamps
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
   HIP_TRY(hipMalloc(&c->status, 2 * sizeof(int)));      // [0] status word, [1] kept rank of the last adaptive step
   HIP_TRY(hipMemsetAsync(c->status, 0, 2 * sizeof(int), c->stream));
@@ -1376,9 +1376,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
   if (c->last_bsize <= 0) return fail(TNML_ERR_STATE, "no step has run yet");
   HIP_TRY(hipSetDevice(c->device));
   const size_t Bs = c->last_bsize;
-  std::vector<double> hbuf(4 * Bs + kDbgSigma + 128);   // tensors, sigma, 5 scalars, stamps
+  std::vector<double> hbuf(4 * Bs + kDbgSigma + kDbgScalars + 8);   // tensors, sigma, 5 scalars, stamps
   HIP_TRY(hipMemcpyAsync(hbuf.data(), c->dbg, (4 * Bs + kDbgSigma + 5) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + kDbgSigma + 5, c->dbg + 4 * c->bmax + kDbgSigma + 5, 115 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hbuf.data() + 4 * Bs + kDbgSigma + 5, c->dbg + 4 * c->bmax + kDbgSigma + 5, (kDbgScalars - 5) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   auto tensor_out = [&](size_t block) -> int {
     if (capacity < Bs) return fail(TNML_ERR_ARG, "capacity too small");
@@ -1406,9 +1406,9 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
       if (n_out) *n_out = c->last_n;
       return TNML_OK;
     case TNML_DBG_L2:
-      if (capacity < 120) return fail(TNML_ERR_ARG, "capacity too small");
-      memcpy(out, hbuf.data() + 4 * Bs + kDbgSigma, 120 * sizeof(double));
-      if (n_out) *n_out = 120;
+      if (capacity < (size_t)kDbgScalars) return fail(TNML_ERR_ARG, "capacity too small");
+      memcpy(out, hbuf.data() + 4 * Bs + kDbgSigma, kDbgScalars * sizeof(double));
+      if (n_out) *n_out = kDbgScalars;
       return TNML_OK;
   }
   return fail(TNML_ERR_ARG, "unknown debug selector %d", what);

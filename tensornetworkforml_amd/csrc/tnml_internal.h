@@ -15,6 +15,7 @@ constexpr int kTS = 32;         // samples per workgroup in the wide step kernel
 constexpr int kWideThreads = 1024; // 4 waves per SIMD: the v1 formulation is latency-bound
 constexpr int kNarrowThreads = 1024;
 constexpr int kMetricSlots = 4;    // per-slab tail: correct count, sum|y-fa|, non-finite count, pad
+constexpr int kDbgScalars = 120 + 16 * 12;   // 5 scalars + 115 stamps + (experiment builds) 12 probe points x 16 waves
 constexpr int kDbgSigma = 128;     // capture block: 4 tensors, then this many singular values, then scalars
 constexpr double kCholThrSmall = 0.35;     // the same for matrices with n < 32
 constexpr double kCholThrDefault = 0.22;   // off(G)/trace(G) above which the Cholesky step pays off (kernels_narrow.hip phase 6b)

@@ -50,6 +50,13 @@ def stamp_line(tag, sc):
         print('   y-stamps (cycles since kernel start):', ' | '.join('%s %d' % (names[i], sc[61 + i]) for i in range(16) if names[i] and sc[61 + i] > 0))
     if len(sc) > 93:
         print('   per wave (work cycles, barrier wait, role rank): ' + ' '.join('w%d:%d/%d/r%d' % (i, int(sc[77 + i] % 1e5), int(sc[77 + i] // 1e5), round((sc[77 + i] % 1) * 1e3) - 1) for i in range(16)))
+    if len(sc) >= 120 + 192 and sc[120] > 0:
+        w = np.array(sc[120:120 + 192]).reshape(16, 12)
+        base = w[0, 0]
+        print('   per-wave probe points (cycles since wave 0 started; rows = probe points, columns = waves 0..15):')
+        for i in range(12):
+            if w[:, i].max() > 0:
+                print('     p%-2d ' % i + ' '.join('%6d' % (x - base if x > 0 else -1) for x in w[:, i]))
     if len(sc) > 13:
         print('   post split: sort %d / cores %d / norm env + metrics %d cycles' % (sc[11], sc[12], sc[13]))
 
