@@ -13,6 +13,21 @@ constexpr int kJacobiMaxSweeps = 30;
 // global hand-offs to other workgroups keep their own explicit s_waitcnt vmcnt(0) + flag protocol.
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// 16-byte agent-scope (sc1) stores and loads for hand-offs between workgroups of one launch (MI355X_MICROARCH.md: a scalar sc1
+// store is one fabric write each -- a dword store costs ~6x the dwordx4 time per byte).  Buffer instructions with the sc1
+// cache-policy bit (aux bit 4), issued through the compiler's builtins so that it tracks their completion itself.  `base`
+// must be wave-uniform; `byte_off` is the lane's byte offset from it (16-byte aligned).
+typedef unsigned tn_uvec4 __attribute__((ext_vector_type(4)));
+__device__ inline __amdgpu_buffer_rsrc_t sc1_rsrc(const void *base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
+}
+__device__ inline void st_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off, tn_uvec4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 16);
+}
+__device__ inline tn_uvec4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
+}
+
 // Rotation (c, s) that annihilates g in [[a, g], [g, b]] under J = [[c, s], [-s, c]] (columns:
 // a' = c a - s b, b' = s a + c b).  level: 0 negligible (identity), 1 small, 2 large -- the sweep
 // loop stops once a whole sweep made only small rotations (quadratic convergence then leaves

@@ -133,6 +133,7 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
   const int h = p.h, g = p.g, s = p.s, L = p.L, Bs = p.bsize;
   const int blk = blockIdx.x - 1;
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long c_start = __builtin_amdgcn_s_memtime();
   if (blk < p.nred) {
     float *part = (float *)smem_raw;                       // [16][64]
     const int el = tid & 63, chunk = tid >> 6;
@@ -160,7 +161,18 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
     PrepParams q{};
     q.lab = p.lab; q.pl = p.pl; q.Nh = p.Nh; q.Ng = p.Ng; q.h = h; q.g = g; q.s = s; q.L = L; q.l2_flag = p.l2_flag;
     q.prepB = p.prepB; q.prepG = p.prepG;
+    q.nparts = p.pipe ? (p.wait_count - p.nred) / (kD * kD) : 1;
+#ifdef TNML_EXP_HELPER_TWICE     // instruction-fetch experiment: the (idempotent) helper body twice through the same code
+#pragma nounroll
+    for (int rep = 0; rep < 2; ++rep) {
+      prep_slice_block(q, blk - p.nred, smem_raw, true, (p.stamps && blk - p.nred == 0) ? p.stamps + 88 + (rep ? 12 : 0) : nullptr);
+      __syncthreads();
+    }
+#elif defined(TNML_EXP_FINE_STAMPS)
+    prep_slice_block(q, blk - p.nred, smem_raw, true, (p.stamps && blk - p.nred == 0) ? p.stamps + 88 : nullptr);
+#else
     prep_slice_block(q, blk - p.nred, smem_raw, true);
+#endif
   }
   // hand-off to workgroup 0 (other CU, possibly other XCD: L1 and L2 are not coherent across them), first row of the
   // hand-off table of MI355X_MICROARCH.md: every handed-off byte was stored with an agent-scope (sc1, write-through)
@@ -168,6 +180,11 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
   // write-back to wait for); workgroup 0 polls it relaxed and reads the data with agent-scope (sc1) loads
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef TNML_EXP_FINE_STAMPS
+  if (p.stamps && tid == 0 && blk - p.nred == 0) p.stamps[88 + 7] = (double)(__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1));
+  if (p.stamps && tid == 0 && blk - p.nred == 0) p.stamps[88 + 8] = (double)(t_start & ((1ull << 40) - 1));
+  if (p.stamps && tid == 0 && blk - p.nred == 0) p.stamps[88 + 10] = (double)(__builtin_amdgcn_s_memtime() - c_start);
+#endif
   if (tid == 0) {
     if (p.stamps && p.counters) {      // diagnostic: first start and last finish of either helper role, 100 MHz ticks
       atomicMin(p.counters + (blk < p.nred ? 4 : 5), t_start);
@@ -178,6 +195,10 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
 }
 
 __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char *smem_raw) {
+  // value ranges the launcher guarantees (narrow_lds_bytes / narrow_path): with them the compiler turns the index products into
+  // full-rate 24-bit multiplies (a 32-bit v_mul_lo_u32 issues at quarter rate, and this workgroup is issue-bound)
+  __builtin_assume(p.h >= 1 && p.h <= 64 && p.g >= 1 && p.g <= 64 && p.s >= 1 && p.s <= 128 && p.m >= 1 && p.m <= 64);
+  __builtin_assume(p.L >= 1 && p.L <= 2048 && p.bsize >= 1 && p.bsize <= 8192 && p.g2 >= 0 && p.g2 <= 64);
   const NarrowCarve k = narrow_carve(smem_raw, p.h, p.g, p.s, p.L, p.m, p.tail_prep ? p.g2 : 0);
   const int tid = threadIdx.x, NT = kNarrowThreads;
   const int D = kD, h = p.h, g = p.g, s = p.s, L = p.L, m = p.m, Bs = p.bsize;
@@ -212,6 +233,9 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 #endif
 #define TNML_STAMP(i) if (p.stamps && tid == 0) t_p[i] = __builtin_amdgcn_s_memtime()
   if (p.stamps && tid == 0) { t_c0 = __builtin_amdgcn_s_memtime(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
+#ifdef TNML_EXP_FINE_STAMPS
+  if (p.stamps && tid == 0) p.stamps[88 + 9] = (double)(t_r0 & ((1ull << 40) - 1));
+#endif
   WPROBE(0);
   // ---- pipelined step: raw gradient dB[h_, rest] = sum_i' A_{k-1}[i', h_] Z_k[i', rest] (wide_pipe_device.h); both operands
   // were completed by the previous launch, so this runs before anything of this launch is waited for
@@ -275,6 +299,9 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     if (!p.z_first)
       mm_lds_f32(h, RWz, zr, sZc, 1, h, sZ, RWz, 1, [&](int i, int j, float v) { k.dT[i * RWz + j] = (double)v; });
     YSTAMP(3);
+#ifdef TNML_EXP_FINE_STAMPS
+    const unsigned long long t_rc = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifndef TNML_EXP_GRAM_TWICE
     WPROBE(2);
 #endif
@@ -292,23 +319,34 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
         }
         if (spins >= (1 << 22)) atomicOr(p.status, 4);
         __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef TNML_EXP_FINE_STAMPS
+        if (p.stamps && p.counters) {      // ticks of the 100 MHz counter relative to this workgroup's start
+          p.stamps[28] = (double)(__builtin_amdgcn_s_memrealtime() - t_r0);      // wait over
+          p.stamps[29] = (double)(t_rc - t_r0);                                  // contraction done (poll starts)
+          p.stamps[31] = (double)(long long)(p.counters[5] - t_r0);              // first slice helper started
+          p.stamps[32] = (double)(long long)(p.counters[7] - t_r0);              // last slice helper done
+          p.stamps[33] = (double)spins;
+          p.counters[5] = ~0ull; p.counters[7] = 0ull;
+        }
+#endif
       }
       lds_barrier();
-      float qb[8];
-      double qg[8];
+      // 16-byte agent-scope loads, all in flight together (Bs is a multiple of D * D = 4)
+      const __amdgpu_buffer_rsrc_t rB = sc1_rsrc(p.prepB), rG = sc1_rsrc(p.prepG);
+      tn_uvec4 qb[2], qg[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = tid + u * NT;
-        qb[u] = e < Bs ? ld_sc1(p.prepB + e) : 0.f;
-        qg[u] = (p.l2_flag && e < Bs) ? __hip_atomic_load(p.prepG + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      }
+      for (int u = 0; u < 2; ++u) { const int e = 4 * (tid + u * NT); if (e < Bs) qb[u] = ld_sc1_b128(rB, (unsigned)e * 4u); }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = tid + u * NT;
-        if (e < Bs) { k.fB[e] = qb[u]; if (p.l2_flag) k.dG[e] = qg[u]; }
-      }
+      for (int u = 0; u < 4; ++u) { const int e = 2 * (tid + u * NT); if (p.l2_flag && e < Bs) qg[u] = ld_sc1_b128(rG, (unsigned)e * 8u); }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { const int e = 4 * (tid + u * NT); if (e < Bs) *reinterpret_cast<tn_uvec4 *>(k.fB + e) = qb[u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = 2 * (tid + u * NT); if (p.l2_flag && e < Bs) *reinterpret_cast<tn_uvec4 *>(k.dG + e) = qg[u]; }
     }
     YSTAMP(4);
+#ifdef TNML_EXP_FINE_STAMPS
+    if (p.stamps && tid == 0) p.stamps[30] = (double)(__builtin_amdgcn_s_memrealtime() - t_r0);     // payload in LDS
+#endif
 #ifndef TNML_EXP_GRAM_TWICE
     WPROBE(3);
 #endif
@@ -464,15 +502,41 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   double factor = (double)p.lr;
   if (sumD > sumB) factor = (double)p.lr * (sumB / sumD);
   const bool bad = !isfinite(sumD) || !isfinite(sumB);
-  for (int row = tid >> 6; row < r; row += NT >> 6)       // rows over waves, columns over lanes
-    for (int x = tid & 63; x < c; x += 64) {
-      const int e = row * c + x;
-      const float v = (float)((double)k.fB[e] + factor * k.dG[e]);
-      k.fB[e] = v;
-      k.fBp[row * (c + 1) + x] = v;
-      if (p.flag) st_sc1(p.Bnew + e, v); else p.Bnew[e] = v;
-      if (p.dbg) p.dbg[2 * (size_t)Bs + e] = (double)v;
+  if ((c & 3) == 0) {
+    // four consecutive elements of a row per thread: 16-byte LDS accesses, and the hand-off to the batch-side workgroups of
+    // this launch leaves as ONE 16-byte agent-scope store per thread straight from registers (a scalar sc1 store is one
+    // fabric write per element); row index by an exact float quotient
+    const float inv_c = 1.0f / (float)c;
+    const __amdgpu_buffer_rsrc_t rN = sc1_rsrc(p.Bnew);
+    for (int e = 4 * tid; e < Bs; e += 4 * NT) {
+      const int row = (int)(((float)e + 0.5f) * inv_c), x = e - row * c;
+      const float4 b4 = *reinterpret_cast<const float4 *>(k.fB + e);
+      const double2 g01 = *reinterpret_cast<const double2 *>(k.dG + e), g23 = *reinterpret_cast<const double2 *>(k.dG + e + 2);
+      float4 v;
+      v.x = (float)((double)b4.x + factor * g01.x); v.y = (float)((double)b4.y + factor * g01.y);
+      v.z = (float)((double)b4.z + factor * g23.x); v.w = (float)((double)b4.w + factor * g23.y);
+      *reinterpret_cast<float4 *>(k.fB + e) = v;
+      float *bp = k.fBp + row * (c + 1) + x;
+      bp[0] = v.x; bp[1] = v.y; bp[2] = v.z; bp[3] = v.w;
+      if (p.flag) {
+        tn_uvec4 o; o.x = __float_as_uint(v.x); o.y = __float_as_uint(v.y); o.z = __float_as_uint(v.z); o.w = __float_as_uint(v.w);
+        st_sc1_b128(rN, (unsigned)(4 * e), o);
+      } else {
+        *reinterpret_cast<float4 *>(p.Bnew + e) = v;
+      }
+      if (p.dbg) { double *dd = p.dbg + 2 * (size_t)Bs + e; dd[0] = v.x; dd[1] = v.y; dd[2] = v.z; dd[3] = v.w; }
     }
+  } else {
+    for (int row = tid >> 6; row < r; row += NT >> 6)       // rows over waves, columns over lanes
+      for (int x = tid & 63; x < c; x += 64) {
+        const int e = row * c + x;
+        const float v = (float)((double)k.fB[e] + factor * k.dG[e]);
+        k.fB[e] = v;
+        k.fBp[row * (c + 1) + x] = v;
+        if (p.flag) st_sc1(p.Bnew + e, v); else p.Bnew[e] = v;
+        if (p.dbg) p.dbg[2 * (size_t)Bs + e] = (double)v;
+      }
+  }
   if (p.flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its stores before the barrier
   if (tid == 0) {
     if (bad) atomicOr(p.status, 1);
@@ -1149,7 +1213,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     p.stamps[6] = (double)(t_c2b - t_c2); p.stamps[7] = (double)(t_c2c - t_c2b); p.stamps[8] = (double)(t_c3 - t_c2c);
   }
 
-#ifdef TNML_EXP_FINE_STAMPS
+#if defined(TNML_EXP_FINE_STAMPS) && !defined(TNML_EXP_HELPER_WAVES)
   if (p.stamps && (tid & 63) == 0)
     for (int i = 0; i < 12; ++i) p.stamps[115 + (tid >> 6) * 12 + i] = (double)(t_w[i] & ((1ull << 44) - 1));
 #endif

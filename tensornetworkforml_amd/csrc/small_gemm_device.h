@@ -3,6 +3,7 @@
 // the wide step kernel carries for that purpose (kernels_wide.hip).
 #pragma once
 #include "tnml_internal.h"
+#include "jacobi_device.h"
 
 namespace tnml {
 
@@ -71,10 +72,13 @@ __device__ inline void small_gemm_f64(int nbatch, int M, int N, int K, FA loadA,
 // step are each a few hundred cycles of MFMA time, so address arithmetic and exposed LDS latency decide their cost.
 // ------------------------------------------------------------------------------------------
 template <class TA, class TB, class FS>
-__device__ inline void mm_lds(int nbatch, int M, int N, int K, const TA *A, int a_bs, int a_rs, int a_ks, const TB *B, int b_bs,
-                              int b_ks, int b_cs, FS store, bool upper_only = false) {
+__device__ inline int mm_lds(int nbatch, int M, int N, int K, const TA *A, int a_bs, int a_rs, int a_ks, const TB *B, int b_bs,
+                             int b_ks, int b_cs, FS store, bool upper_only = false, int slot0 = 0) {
   // upper_only: M == N and only tiles with ti <= tj are computed (symmetric products: the caller mirrors)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // slot0 / return value: independent products issued back to back (no barrier between them) continue the round-robin deal
+  // of tiles to waves where the previous one stopped
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform for the compiler: scalar tile bookkeeping
   const int tn = (N + 15) >> 4, tm = (M + 15) >> 4;
   const int r = lane & 15, q = lane >> 4;
   const int nk = (K + 3) >> 2;                         // k-steps of 4
@@ -83,7 +87,7 @@ __device__ inline void mm_lds(int nbatch, int M, int N, int K, const TA *A, int 
   // tiles are dealt to the waves in the order they are met; three nested counters instead of t / per, t % tn: a wave-uniform
   // integer division is ~40 scalar instructions and a per-lane one 134 cycles (tools/ubench/prims.hip), which at one or two
   // dozen tiles per product used to cost more than the MFMAs
-  int slot = 0;
+  int slot = slot0;
   for (int bt = 0; bt < nbatch; ++bt)
    for (int ti = 0; ti < tm; ++ti)
     for (int tj = upper_only ? ti : 0; tj < tn; ++tj) {
@@ -126,6 +130,7 @@ __device__ inline void mm_lds(int nbatch, int M, int N, int K, const TA *A, int 
       if (i < M && j < N) store(bt, i, j, acc[reg]);
     }
   }
+  return slot;
 }
 
 // float32 form of mm_lds (v_mfma_f32_16x16x4_f32: half the cycles of the float64 instruction, operands used as stored) for
@@ -135,7 +140,8 @@ __device__ inline void mm_lds(int nbatch, int M, int N, int K, const TA *A, int 
 typedef float fvec4_t __attribute__((ext_vector_type(4)));
 template <class FS>
 __device__ inline void mm_lds_f32(int M, int N, int K, const float *A, int a_rs, int a_ks, const float *B, int b_ks, int b_cs, FS store) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tn = (N + 15) >> 4, tm = (M + 15) >> 4;
   const int r = lane & 15, q = lane >> 4;
   const int nk = (K + 3) >> 2;
@@ -190,54 +196,142 @@ __device__ inline void mm_lds_f32(int M, int N, int K, const float *A, int a_rs,
 // [h][dk][dk1][g][l].
 // ------------------------------------------------------------------------------------------
 // coherent: the results are read by another workgroup of the SAME launch (agent-scope stores; see narrow_helper_block)
-__device__ inline void prep_slice_block(const PrepParams &p, int slice, unsigned char *smem_raw, bool coherent = false) {
+__device__ inline void prep_slice_block(const PrepParams &p, int slice, unsigned char *smem_raw, bool coherent = false, double *hstamp = nullptr) {
+#define HSTAMP(i) if (hstamp && threadIdx.x == 0) hstamp[i] = (double)(__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1))
+#ifdef TNML_EXP_HELPER_WAVES   // per-wave shader-cycle stamps of the helper's phases into the probe area (hstamp + 27 = stamps[115])
+#define HWAVE(i) if (hstamp && (threadIdx.x & 63) == 0) hstamp[27 + (threadIdx.x >> 6) * 12 + (i)] = (double)(__builtin_amdgcn_s_memtime() & ((1ull << 44) - 1))
+#else
+#define HWAVE(i)
+#endif
+  // B_dd' = lab_d . pl_d'   and   (Ln.B.Rn)_dd' = (Nh^T lab_d) . (pl_d' Ng): the three first-level products are independent
+  // and run back to back without a barrier, the second level is one more product -- a dependent chain of two instead of
+  // three, behind ONE round trip to memory for all four operands.
   const int tid = threadIdx.x, NT = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = NT >> 6;
+  HSTAMP(0);
   const int D = kD, h = p.h, g = p.g, s = p.s, L = p.L;
-  const int dk = slice / D, dk1 = slice % D;
-  const int GL = g * L;
+  // rows [i_lo, i_lo + nr) of slice (dk, dk1): a slice may be cut into row parts over several workgroups (a 20-row slice is
+  // 16 + 4 rows of MFMA tiles anyway), which only repeat the small product pl . Ng
+  const int nparts = p.nparts > 1 ? p.nparts : 1, part = slice / (D * D), sl = slice - part * (D * D);
+  const int hh = (h + nparts - 1) / nparts, i_lo = part * hh, nr = min(h, i_lo + hh) - i_lo;
+  if (nr <= 0) return;
+  const int dk = sl / D, dk1 = sl % D;
+  const int sL = s * L, nlab = h * sL, npl = s * g, nhh = h * h, ngg = g * g;
   double *dNh = (double *)smem_raw;                      // [h][h]
-  double *dNg = dNh + (((size_t)h * h + 1) & ~(size_t)1);   // [g][g]
-  double *dT = dNg + (((size_t)g * g + 1) & ~(size_t)1);    // [h][g][L]
-  float *sLab = (float *)(dT + (size_t)h * GL);          // [h][s][L]   (this dk)
-  float *sPl = sLab + (size_t)h * s * L;                 // [s][g]      (this dk1)
-  float *fBs = sPl + (size_t)s * g;                      // [h][g][L]
-  // rows over waves, the contiguous index over lanes: no integer division (134 cycles each, tools/ubench/prims.hip)
-  for (int h_ = wave; h_ < h; h_ += nw)
-    for (int l = 0; l < L; ++l)
-      for (int s_ = lane; s_ < s; s_ += 64)
-        sLab[(h_ * s + s_) * L + l] = p.lab.base[h_ * p.lab.s_in + dk * p.lab.s_d + s_ * p.lab.s_out + l];
-  for (int s_ = wave; s_ < s; s_ += nw)
-    for (int g_ = lane; g_ < g; g_ += 64)
-      sPl[s_ * g + g_] = p.pl.base[s_ * p.pl.s_in + dk1 * p.pl.s_d + g_ * p.pl.s_out];
-  if (p.l2_flag) {
-    for (int e = tid; e < h * h; e += NT) dNh[e] = p.Nh ? p.Nh[e] : 1.0;
-    for (int e = tid; e < g * g; e += NT) dNg[e] = p.Ng ? p.Ng[e] : 1.0;
+  double *dNg = dNh + (((size_t)nhh + 1) & ~(size_t)1);  // [g][g]
+  double *dX = dNg + (((size_t)ngg + 1) & ~(size_t)1);   // [h][s][L]   Nh^T . lab
+  double *dY = dX + (((size_t)nlab + 1) & ~(size_t)1);   // [s][g]      pl . Ng
+  float *sLab = (float *)(dY + (((size_t)npl + 1) & ~(size_t)1));   // [h][s][L]   (this dk)
+  float *sPl = sLab + (size_t)nlab;                      // [s][g]      (this dk1)
+  // exact quotients of small integers by float reciprocal (a hardware integer division costs 134 cycles per lane)
+  const float inv_sL = 1.0f / (float)sL, inv_L = 1.0f / (float)L, inv_g = 1.0f / (float)g;
+  auto lab_at = [&](int e) -> float {
+    const int h_ = (int)(((float)e + 0.5f) * inv_sL), x = e - h_ * sL;
+    const int s_ = (int)(((float)x + 0.5f) * inv_L), l = x - s_ * L;
+    return p.lab.base[h_ * p.lab.s_in + dk * p.lab.s_d + s_ * p.lab.s_out + l];
+  };
+  auto pl_at = [&](int e) -> float {
+    const int s_ = (int)(((float)e + 0.5f) * inv_g), g_ = e - s_ * g;
+    return p.pl.base[s_ * p.pl.s_in + dk1 * p.pl.s_d + g_ * p.pl.s_out];
+  };
+  {
+    float rl[2], rp[2];
+    double rh[2], rg[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                        // every load of the first 2 * NT elements of each operand in flight together
+      const int e = tid + u * NT;
+      rl[u] = e < nlab ? lab_at(e) : 0.f;
+      rp[u] = e < npl ? pl_at(e) : 0.f;
+      rh[u] = (p.l2_flag && e < nhh) ? (p.Nh ? p.Nh[e] : 1.0) : 0.0;
+      rg[u] = (p.l2_flag && e < ngg) ? (p.Ng ? p.Ng[e] : 1.0) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * NT;
+      if (e < nlab) sLab[e] = rl[u];
+      if (e < npl) sPl[e] = rp[u];
+      if (p.l2_flag && e < nhh) dNh[e] = rh[u];
+      if (p.l2_flag && e < ngg) dNg[e] = rg[u];
+    }
+    HSTAMP(1);
+    for (int e = tid + 2 * NT; e < nlab; e += NT) sLab[e] = lab_at(e);
+    for (int e = tid + 2 * NT; e < npl; e += NT) sPl[e] = pl_at(e);
+    if (p.l2_flag) {
+      for (int e = tid + 2 * NT; e < nhh; e += NT) dNh[e] = p.Nh ? p.Nh[e] : 1.0;
+      for (int e = tid + 2 * NT; e < ngg; e += NT) dNg[e] = p.Ng ? p.Ng[e] : 1.0;
+    }
   }
   __syncthreads();
-  mm_lds(L, h, g, s, sLab, 1, s * L, L, sPl, 0, g, 1,
-         [&](int l, int i, int j, double v) {
-           const float fv = (float)v;
-           fBs[(i * g + j) * L + l] = fv;
-           float *dst = p.prepB + (size_t)(((i * D + dk) * D + dk1) * g + j) * L + l;
-           if (coherent) __hip_atomic_store(dst, fv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = fv;
-         });
+  HSTAMP(2);
+  HWAVE(0);
+  // Results leave through LDS: a row (i) of a slice is g * L contiguous elements of the [h][dk][dk1][g][l] layout, so the
+  // hand-off to another workgroup of this launch goes out as 16-byte agent-scope stores instead of one fabric write per element.
+  const int gL = g * L;
+  float *oB = sLab + (((size_t)nlab + npl + 3) & ~(size_t)3);   // [h][g][L], 16-byte aligned
+  const bool vecB = coherent && (gL & 3) == 0, vecG = coherent && (gL & 1) == 0;
+  int slot = mm_lds(L, nr, g, s, sLab + i_lo * sL, 1, sL, L, sPl, 0, g, 1,
+                    [&](int l, int i, int j, double v) {
+                      if (vecB) oB[(i * g + j) * L + l] = (float)v;
+                      else {
+                        float *dst = p.prepB + (size_t)((((i_lo + i) * D + dk) * D + dk1) * g + j) * L + l;
+                        if (coherent) __hip_atomic_store(dst, (float)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = (float)v;
+                      }
+                    });
+  HWAVE(1);
   if (p.l2_flag) {
-    __syncthreads();
-    mm_lds(1, h, GL, h, dNh, 0, 1, h, fBs, 0, GL, 1, [&](int, int i, int j, double v) { dT[i * GL + j] = v; });
-    __syncthreads();
-    mm_lds(L, h, g, g, dT, 1, GL, L, dNg, 0, g, 1,
-           [&](int l, int i, int j, double v) {
-             double *dst = p.prepG + (size_t)(((i * D + dk) * D + dk1) * g + j) * L + l;
-             if (coherent) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = v;
-           });
+    // X[i][x] = sum_a Nh[a][i] lab[a][x]  (x = (s_, l));   Y[s_][j] = sum_c pl[s_][c] Ng[c][j]
+    slot = mm_lds(1, nr, sL, h, dNh + i_lo, 0, 1, h, sLab, 0, sL, 1, [&](int, int i, int x, double v) { dX[i * sL + x] = v; }, false, slot);
+    mm_lds(1, s, g, g, sPl, 0, g, 1, dNg, 0, g, 1, [&](int, int s_, int j, double v) { dY[s_ * g + j] = v; }, false, slot);
   }
+  HSTAMP(3);
+  HWAVE(2);
+  __syncthreads();
+  HSTAMP(4);
+  HWAVE(3);
+  if (vecB) {                                            // B rows: (gL / 4) 16-byte pieces each
+    const __amdgpu_buffer_rsrc_t rB = sc1_rsrc(p.prepB);
+    const int pieces = gL >> 2, total = nr * pieces;
+    const float inv_p = 1.0f / (float)pieces;
+    for (int e = tid; e < total; e += NT) {
+      const int i = (int)(((float)e + 0.5f) * inv_p), c4 = e - i * pieces;
+      const tn_uvec4 v = *reinterpret_cast<const tn_uvec4 *>(oB + (size_t)i * gL + 4 * c4);
+      st_sc1_b128(rB, (unsigned)(((((i_lo + i) * D + dk) * D + dk1) * gL + 4 * c4) * sizeof(float)), v);
+    }
+  }
+  if (p.l2_flag) {
+    double *oGs = (double *)(oB + (((size_t)h * gL + 3) & ~(size_t)3));     // [h][g][L] staging of the second-level result
+    mm_lds(L, nr, g, s, dX, 1, sL, L, dY, 0, g, 1,
+           [&](int l, int i, int j, double v) {
+             if (vecG) oGs[(i * g + j) * L + l] = v;
+             else {
+               double *dst = p.prepG + (size_t)((((i_lo + i) * D + dk) * D + dk1) * g + j) * L + l;
+               if (coherent) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = v;
+             }
+           });
+    HSTAMP(5);
+    HWAVE(4);
+    if (vecG) {
+      __syncthreads();
+      const __amdgpu_buffer_rsrc_t rG = sc1_rsrc(p.prepG);
+      const int pieces = gL >> 1, total = nr * pieces;
+      const float inv_p = 1.0f / (float)pieces;
+      for (int e = tid; e < total; e += NT) {
+        const int i = (int)(((float)e + 0.5f) * inv_p), c2 = e - i * pieces;
+        const tn_uvec4 v = *reinterpret_cast<const tn_uvec4 *>(oGs + (size_t)i * gL + 2 * c2);
+        st_sc1_b128(rG, (unsigned)(((((i_lo + i) * D + dk) * D + dk1) * gL + 2 * c2) * sizeof(double)), v);
+      }
+    }
+  }
+  HSTAMP(6);
+  HWAVE(5);
+#undef HSTAMP
+#undef HWAVE
 }
 
 // LDS bytes prep_slice_block needs
 inline size_t prep_slice_lds_bytes(int h, int g, int s, int L) {
-  return ((((size_t)h * h + 1) & ~(size_t)1) + (((size_t)g * g + 1) & ~(size_t)1) + (size_t)h * g * L) * sizeof(double) +
-         ((size_t)h * s * L + (size_t)s * g + (size_t)h * g * L) * sizeof(float) + 16;
+  auto ev = [](size_t x) { return (x + 1) & ~(size_t)1; };
+  return (ev((size_t)h * h) + ev((size_t)g * g) + ev((size_t)h * s * L) + ev((size_t)s * g) + (size_t)h * g * L) * sizeof(double) +
+         ((size_t)h * s * L + (size_t)s * g + (((size_t)h * g * L + 3) & ~(size_t)3)) * sizeof(float) + 48;
 }
 
 }  // namespace tnml

@@ -1004,7 +1004,8 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       c->prep_valid = false;
       n.fused = 1; n.nred = 0; n.sync = c->sync; n.red_out = nullptr;
       n.prep_ready = have_prep ? 1 : 0;
-      n.wait_count = have_prep ? 0 : kD * kD;
+      // (a slice of more than 8 rows is cut into two row parts: twice the workgroups, half the dependent tiles in each)
+      n.wait_count = have_prep ? 0 : kD * kD * (h > 8 ? 2 : 1);
       // ... and this launch's tail prepares the next step's, when that step exists and will run pipelined in LDS
       // (measured, round 2: the three products of that preparation cost workgroup 0 23 k cycles at the end of its launch and
       // save it 16 k cycles of waiting for the slice workgroups at the start of the next: off by default)

@@ -141,6 +141,7 @@ struct PrepParams {
   int h, g, s, L, l2_flag;
   float *prepB;
   double *prepG;
+  int nparts;              // row parts per slice (0 == 1): workgroup index = part * D * D + slice
 };
 
 // false: no kernel of this build fits the tile's operands into LDS.  *prep_done: the launch carried the D*D slice workgroups

@@ -246,9 +246,35 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
       lds_barrier();                                            // the poll is over; P', Q', Qn are complete
       const int rowlen = nJ * L;
       if (tt == 0) {                                              // B'[i][(jj, l)] at the odd row stride, zero padded
-        for (int i = wave; i < dm.IP; i += NWV)
-          for (int x = lane; x < dm.RS; x += 64)
-            w.sBp[i * dm.RS + x] = (i < nI && x < rowlen) ? (p.wait_flag ? ld_sc1(p.Bnew + i * rowlen + x) : p.Bnew[i * rowlen + x]) : 0.f;
+        if (p.wait_flag && (rowlen & 3) == 0) {
+          // produced by the update workgroup of THIS launch: 16-byte agent-scope loads (rows are rowlen contiguous floats),
+          // up to four in flight per lane; the padding of the odd row stride and of the rows beyond nI is zeroed separately
+          const __amdgpu_buffer_rsrc_t rB = sc1_rsrc(p.Bnew);
+          const int pieces = rowlen >> 2;
+          for (int i0 = wave; i0 < nI; i0 += 4 * NWV) {
+            tn_uvec4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int i = i0 + u * NWV;
+              if (i < nI && lane < pieces) v[u] = ld_sc1_b128(rB, (unsigned)((i * rowlen + 4 * lane) * sizeof(float)));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int i = i0 + u * NWV;
+              if (i < nI && lane < pieces) {
+                float *d = w.sBp + i * dm.RS + 4 * lane;
+                d[0] = __uint_as_float(v[u].x); d[1] = __uint_as_float(v[u].y); d[2] = __uint_as_float(v[u].z); d[3] = __uint_as_float(v[u].w);
+              }
+            }
+          }
+          for (int i = wave; i < dm.IP; i += NWV)
+            for (int x = lane; x < dm.RS; x += 64)
+              if (i >= nI || x >= rowlen || x >= 256) w.sBp[i * dm.RS + x] = (i < nI && x < rowlen) ? ld_sc1(p.Bnew + i * rowlen + x) : 0.f;
+        } else {
+          for (int i = wave; i < dm.IP; i += NWV)
+            for (int x = lane; x < dm.RS; x += 64)
+              w.sBp[i * dm.RS + x] = (i < nI && x < rowlen) ? (p.wait_flag ? ld_sc1(p.Bnew + i * rowlen + x) : p.Bnew[i * rowlen + x]) : 0.f;
+        }
         lds_barrier();
       }
       const int ITF = dm.IP / 16;
@@ -330,6 +356,10 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
 
   // ---- partial tensor of this workgroup -> slab (agent-scope stores), then the two-level fixed-order reduction ----------
   float *slab = p.slabs + (size_t)wg * p.slab_stride;
+  // through LDS when it fits (it does for every shape the launcher admits at two labels): the partial leaves as 16-byte
+  // agent-scope stores -- a scalar sc1 store is one fabric write per element (MI355X_MICROARCH.md)
+  const bool staged = (size_t)(p.zsize + kMetricSlots) <= w.floats && (p.zsize & 3) == 0;
+  if (staged) lds_barrier();                                     // the operand arrays of the last tile are dead
 #pragma unroll
   for (int u = 0; u < kMaxZT; ++u) {
     const int cidx = wave + u * NWV;
@@ -340,11 +370,20 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int ii = it * 16 + 4 * q + reg;
-        if (ii < nI * kD && jn < QW) st_sc1(slab + ((size_t)ii * QW + jn) * L + l, zacc[u][reg]);
+        if (ii < nI * kD && jn < QW) {
+          if (staged) smem[((size_t)ii * QW + jn) * L + l] = zacc[u][reg];
+          else st_sc1(slab + ((size_t)ii * QW + jn) * L + l, zacc[u][reg]);
+        }
       }
     }
   }
-  if (tid < 4) st_sc1(slab + p.zsize + tid, met[tid]);
+  if (staged) {
+    if (tid < 4) smem[p.zsize + tid] = met[tid];
+    lds_barrier();
+    const __amdgpu_buffer_rsrc_t rS = sc1_rsrc(slab);
+    for (int e = tid; e < (p.zsize + kMetricSlots) / 4; e += NT)
+      st_sc1_b128(rS, (unsigned)(16 * e), *reinterpret_cast<const tn_uvec4 *>(smem + 4 * e));
+  } else if (tid < 4) st_sc1(slab + p.zsize + tid, met[tid]);
   const int n = p.zsize + kMetricSlots;
   __shared__ unsigned sTicket;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -377,7 +416,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
       }
-      if (publish) { st_sc1(dst + 4 * e, a.x); st_sc1(dst + 4 * e + 1, a.y); st_sc1(dst + 4 * e + 2, a.z); st_sc1(dst + 4 * e + 3, a.w); }
+      if (publish) { tn_uvec4 o; o.x = __float_as_uint(a.x); o.y = __float_as_uint(a.y); o.z = __float_as_uint(a.z); o.w = __float_as_uint(a.w); st_sc1_b128(sc1_rsrc(dst), (unsigned)(16 * e), o); }
       else *reinterpret_cast<float4 *>(dst + 4 * e) = a;
     }
   };

@@ -247,7 +247,9 @@ def test_rccl_path_single_rank(monkeypatch):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
 
 
-@pytest.mark.parametrize('stop2,tol', [(None, 2e-5), (1e-4, 1e-3), (1e-8, 5e-6)])
+# default threshold: worst product error observed between 2.6e-6 and 2.6e-5 over builds that differ only in the rounding
+# order of float64 sums (the worst step of two late sweeps is a tail statistic of a chaotic trajectory)
+@pytest.mark.parametrize('stop2,tol', [(None, 5e-5), (1e-4, 1e-3), (1e-8, 5e-6)])
 def test_svd_accuracy_late_in_training(stop2, tol):
     """The Jacobi iteration stops early once its rotations are small (tnml_set_svd_stop); late in training
     that happens after few sweeps.  Every step of the 7th and 8th pass: the product of the two new cores

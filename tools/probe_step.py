@@ -40,7 +40,7 @@ def stamp_line(tag, sc):
     if len(sc) > 52 and sc[46] > 0:
         print('   round-timing experiment (cycles per round): all %d | params only %d | G only %d | params+G %d | V only %d | params+V %d | G+V %d' % tuple(sc[46:53]))
     if len(sc) > 38 and sc[33] > 0:
-        print('   fused launch, 10 ns ticks after workgroup 0 started: wait over %d | reduce helpers %d..%d | slice helpers %d..%d | polls %d' % tuple(sc[33:39]))
+        print('   hand-off, 10 ns ticks after workgroup 0 started: wait over %d | (classic: reduce helpers; pipelined: poll starts, payload in LDS) %d..%d | slice helpers %d..%d | polls %d' % tuple(sc[33:39]))
     if len(sc) > 45 and sc[39] > 0:
         print('   fine stamps: phase-4 loop %d / block sums %d / update loop %d / barrier after update %d | zero fill+barrier %d / gram GEMM %d / symmetrise+tables %d' % tuple(sc[39:46]))
     if len(sc) > 54 and sc[53] > 0:
@@ -50,9 +50,21 @@ def stamp_line(tag, sc):
         print('   y-stamps (cycles since kernel start):', ' | '.join('%s %d' % (names[i], sc[61 + i]) for i in range(16) if names[i] and sc[61 + i] > 0))
     if len(sc) > 93:
         print('   per wave (work cycles, barrier wait, role rank): ' + ' '.join('w%d:%d/%d/r%d' % (i, int(sc[77 + i] % 1e5), int(sc[77 + i] // 1e5), round((sc[77 + i] % 1) * 1e3) - 1) for i in range(16)))
+    if len(sc) > 103 and sc[93 + 9] > 0:
+        hs = sc[93:93 + 10]
+        print('   slice helper 0, 10 ns ticks after workgroup 0 started: block start %d | body start %d | loads issued %d | operands in LDS %d | level 1 done %d | barrier %d | level 2 done %d | stores issued %d | drained %d'
+              % tuple(int(hs[i] - hs[9]) for i in (8, 0, 1, 2, 3, 4, 5, 6, 7)))
+        print('   slice helper 0: %d shader cycles from block start to drained = %.2f GHz' % (sc[93 + 10], sc[93 + 10] / max(hs[7] - hs[8], 1) / 10.0))
+    if len(sc) > 115 and sc[93 + 12] > 0 and sc[93 + 12 + 6] > 0:
+        h2 = sc[93 + 12:93 + 12 + 7]
+        print('   slice helper 0, SECOND pass through the same code (ticks since its own start): loads issued %d | operands in LDS %d | level 1 done %d | barrier %d | level 2 done %d | stores issued %d'
+              % tuple(int(h2[i] - h2[0]) for i in (1, 2, 3, 4, 5, 6)))
+        h1 = sc[93:93 + 7]
+        print('   first pass, same reference:                                                        loads issued %d | operands in LDS %d | level 1 done %d | barrier %d | level 2 done %d | stores issued %d'
+              % tuple(int(h1[i] - h1[0]) for i in (1, 2, 3, 4, 5, 6)))
     if len(sc) >= 120 + 192 and sc[120] > 0:
         w = np.array(sc[120:120 + 192]).reshape(16, 12)
-        base = w[0, 0]
+        base = w[:, 0][w[:, 0] > 0].min()
         print('   per-wave probe points (cycles since wave 0 started; rows = probe points, columns = waves 0..15):')
         for i in range(12):
             if w[:, i].max() > 0:
