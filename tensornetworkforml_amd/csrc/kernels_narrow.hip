@@ -64,27 +64,19 @@ __device__ inline void block_sum3(double &a, double &b, double &c, double *scrat
 
 struct NarrowCarve {
   double *dT, *dG, *Z, *dNh, *dNg, *dLam, *dRed, *dT2, *dCS, *dSq, *dVs;
-  float *fB, *fBp, *sLab, *sPl, *sCb, *sLab2, *sPl2;
-  double *dNg2;
+  float *fB, *fBp, *sLab, *sPl, *sCb;
   int *sOrd, *sFlag, *sPi, *sPiInv, *sWave;
   float *sTail;
   size_t bytes;
 };
 
-// doubles of the tail preparation (phase 12) inside the Jacobi region: T (double), Nh_new (double), B' (float)
-__host__ __device__ inline size_t narrow_tail_doubles(int g, int L, int m, int g2) {
-  const size_t Bs2 = (size_t)m * kD * kD * g2 * L;
-  return Bs2 + (((size_t)m * m + 1) & ~(size_t)1) + (Bs2 + 5) / 2 + 2;
-}
-
-__host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, int g, int s, int L, int m, int g2 = 0) {
+__host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, int g, int s, int L, int m) {
   const int D = kD;
   const size_t Bs = (size_t)h * D * D * g * L;
   const int r = D * h, c = D * g * L;
   const int n = r <= c ? r : c, ne = n + (n & 1);
   size_t zreg = 2 * Bs;
   if ((size_t)4 * ne * ne > zreg) zreg = (size_t)4 * ne * ne;   // G and V, two buffers each, ne x ne
-  if (g2 > 0 && narrow_tail_doubles(g, L, m, g2) > zreg) zreg = narrow_tail_doubles(g, L, m, g2);
   NarrowCarve k;
   double *d = (double *)base;
   k.dT = d; k.dG = d + Bs; k.Z = d; d += zreg;
@@ -96,15 +88,13 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
   k.dCS = d; d += 4 * ne;                   // (c, s, t, -) per pair, two rounds in flight
   k.dSq = d; d += 2 * ne;                   // sigma^(1/2) and sigma^(-1/2) of the kept columns
   k.dVs = d; d += (size_t)ne * m;           // kept eigenvectors, columns in descending order of the eigenvalue
-  k.dNg2 = d; d += ((size_t)g2 * g2 + 1) & ~(size_t)1;     // ahead norm environment of the NEXT step (tail preparation)
   float *f = (float *)d;
   k.fB = f; f += Bs;
   k.fBp = f; f += Bs + (size_t)(D * h < D * g * L ? D * h : D * g * L) + 4;   // rows at stride (cols + 1): bank-conflict-free
   k.sLab = f; f += (size_t)h * D * s * L;
   k.sPl = f; f += (size_t)s * D * g;
   k.sCb = f; f += (size_t)r * m;
-  k.sLab2 = f; f += (size_t)m * c;          // the new label core [s'][(dk1, g_, l)] (float-rounded, as stored)
-  k.sPl2 = f; f += ((size_t)g * kD * g2 + 3) & ~(size_t)3;   // plain core of the next step's ahead site (tail preparation)
+  f += (size_t)m * c;                       // room: the pipelined step stages the reduced pre-gradient in [fBp, sOrd) before its contraction
   int *ip = (int *)f;
   k.sOrd = ip; ip += ne;
   k.sFlag = ip; ip += 8;
@@ -116,8 +106,8 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
   return k;
 }
 
-size_t narrow_lds_bytes(int h, int g, int s, int L, int m, int g2) {
-  return narrow_carve(nullptr, h, g, s, L, m, g2).bytes + 16;
+size_t narrow_lds_bytes(int h, int g, int s, int L, int m) {
+  return narrow_carve(nullptr, h, g, s, L, m).bytes + 16;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -129,11 +119,13 @@ size_t narrow_lds_bytes(int h, int g, int s, int L, int m, int g2) {
 //                               two feature indices, so the four slices are independent
 // ------------------------------------------------------------------------------------------
 __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char *smem_raw) {
-  const int tid = threadIdx.x, NT = kNarrowThreads;
+  const int tid = threadIdx.x;
   const int h = p.h, g = p.g, s = p.s, L = p.L, Bs = p.bsize;
   const int blk = blockIdx.x - 1;
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#ifdef TNML_EXP_FINE_STAMPS
   const unsigned long long c_start = __builtin_amdgcn_s_memtime();
+#endif
   if (blk < p.nred) {
     float *part = (float *)smem_raw;                       // [16][64]
     const int el = tid & 63, chunk = tid >> 6;
@@ -198,8 +190,8 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // value ranges the launcher guarantees (narrow_lds_bytes / narrow_path): with them the compiler turns the index products into
   // full-rate 24-bit multiplies (a 32-bit v_mul_lo_u32 issues at quarter rate, and this workgroup is issue-bound)
   __builtin_assume(p.h >= 1 && p.h <= 64 && p.g >= 1 && p.g <= 64 && p.s >= 1 && p.s <= 128 && p.m >= 1 && p.m <= 64);
-  __builtin_assume(p.L >= 1 && p.L <= 2048 && p.bsize >= 1 && p.bsize <= 8192 && p.g2 >= 0 && p.g2 <= 64);
-  const NarrowCarve k = narrow_carve(smem_raw, p.h, p.g, p.s, p.L, p.m, p.tail_prep ? p.g2 : 0);
+  __builtin_assume(p.L >= 1 && p.L <= 2048 && p.bsize >= 1 && p.bsize <= 8192);
+  const NarrowCarve k = narrow_carve(smem_raw, p.h, p.g, p.s, p.L, p.m);
   const int tid = threadIdx.x, NT = kNarrowThreads;
   const int D = kD, h = p.h, g = p.g, s = p.s, L = p.L, m = p.m, Bs = p.bsize;
   // reduced gradient + metric tail: written by other workgroups of THIS launch when fused -> coherent loads
@@ -244,23 +236,22 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // this workgroup is requested at once (16-byte loads where the layout allows) and lands in LDS after one round trip --
   // a loop of dependent load -> LDS-store iterations costs one round trip per iteration (7 for the reduced pre-gradient).
   const bool fast0 = p.pipe && (size_t)p.z_rows * RWz + (size_t)p.z_rows * h <= (size_t)((float *)k.sOrd - k.fBp) &&
-                     Bs <= 8 * NT && p.z_rows * RWz <= 16 * NT && p.z_rows * h <= 4 * NT && h * h <= 2 * NT && g * g <= 2 * NT &&
-                     g * D * p.g2 <= 2 * NT && p.g2 * p.g2 <= 2 * NT;
+                     Bs <= 8 * NT && p.z_rows * RWz <= 16 * NT && p.z_rows * h <= 4 * NT && h * h <= 2 * NT && g * g <= 2 * NT;
   float *sZ = k.fBp, *sZc = sZ + (size_t)p.z_rows * RWz;
   if (fast0) {
     const int zr = p.z_rows, nz = p.z_first ? 0 : zr * RWz, nzc = p.z_first ? 0 : zr * h;
     const float *zc = p.zcore.base;
     float4 rz[4], rb[2];
     double2 rg[4];
-    float rc[4], rpl[2];
-    double rnh[2], rng[2], rng2[2];
+    float rc[4];
+    double rnh[2], rng[2];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int e = 4 * (tid + u * NT); rz[u] = e < nz ? *reinterpret_cast<const float4 *>(p.zred + e) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int e = 4 * (tid + u * NT); rb[u] = (p.prep_ready && e < Bs) ? *reinterpret_cast<const float4 *>(p.prepB + e) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int e = 2 * (tid + u * NT); rg[u] = (p.prep_ready && p.l2_flag && e < Bs) ? *reinterpret_cast<const double2 *>(p.prepG + e) : make_double2(0.0, 0.0); }
-    const float inv_h = 1.0f / (float)h, inv_g2 = p.g2 > 0 ? 1.0f / (float)p.g2 : 0.f;   // exact quotients for these small integers
+    const float inv_h = 1.0f / (float)h;   // exact quotients for these small integers
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + u * NT, i2 = (int)(((float)e + 0.5f) * inv_h), hh = e - i2 * h;
@@ -271,9 +262,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       const int e = tid + u * NT;
       rnh[u] = (p.Nh && e < h * h) ? p.Nh[e] : 1.0;
       rng[u] = (p.Ng && e < g * g) ? p.Ng[e] : 1.0;
-      rng2[u] = (p.tail_prep && p.Ng2 && e < p.g2 * p.g2) ? p.Ng2[e] : 1.0;
-      const int q2 = (int)(((float)e + 0.5f) * inv_g2), g_ = e - q2 * p.g2;
-      rpl[u] = (p.tail_prep && e < g * D * p.g2) ? p.pl2.base[(q2 / D) * p.pl2.s_in + (q2 % D) * p.pl2.s_d + g_ * p.pl2.s_out] : 0.f;
     }
     YSTAMP(0);
 #pragma unroll
@@ -289,8 +277,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       const int e = tid + u * NT;
       if (e < h * h) k.dNh[e] = rnh[u];
       if (e < g * g) k.dNg[e] = rng[u];
-      if (p.tail_prep && e < p.g2 * p.g2) k.dNg2[e] = rng2[u];
-      if (p.tail_prep && e < g * D * p.g2) k.sPl2[e] = rpl[u];
     }
     YSTAMP(1);
     WPROBE(1);
@@ -419,13 +405,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   if (!fast0) {
     for (int e = tid; e < h * h; e += NT) k.dNh[e] = p.Nh ? p.Nh[e] : 1.0;
     for (int e = tid; e < g * g; e += NT) k.dNg[e] = p.Ng ? p.Ng[e] : 1.0;
-    if (p.tail_prep) {             // operands of the next step that exist already: its plain core and its ahead norm environment
-      for (int e = tid; e < g * D * p.g2; e += NT) {
-        const int g_ = e % p.g2, q2 = e / p.g2;
-        k.sPl2[e] = p.pl2.base[(q2 / D) * p.pl2.s_in + (q2 % D) * p.pl2.s_d + g_ * p.pl2.s_out];
-      }
-      for (int e = tid; e < p.g2 * p.g2; e += NT) k.dNg2[e] = p.Ng2 ? p.Ng2[e] : 1.0;
-    }
   }
   lds_barrier();
 
@@ -1117,7 +1096,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     } else {                                // kk = column index (dk1*g + g_)*L + l -> ahead core
       const int l = kk % L, q = kk / L;
       p.out_ahead[sp * p.oa_s_m + (q / g) * oa_s_d + (q % g) * oa_s_g + l] = v;
-      if (p.tail_prep) k.sLab2[sp * c + kk] = v;
     }
    }
   // long-side factor: (W q_j) / sigma_j^(1/2); columns s', inner index the short one
@@ -1130,7 +1108,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
                      const int dk1 = qq >= g ? 1 : 0;                     // D == 2
                      const float v = (float)(acc * k.dSq[ne + sp]);
                      p.out_ahead[sp * p.oa_s_m + dk1 * oa_s_d + (qq - dk1 * g) * oa_s_g + l] = v;
-                     if (p.tail_prep) k.sLab2[sp * c + qq * L + l] = v;
                    });
   } else {
     // long index = behind group x = (h_, dk) = h_ * D + dk: dk is the batch, rows are h_
@@ -1147,53 +1124,18 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 
   if (p.stamps && tid == 0) t_c2c = __builtin_amdgcn_s_memtime();
   // ---- phase 10: behind norm environment of the next step ------------------------------------------
-  // tail region (phase 12) inside the Jacobi buffers, dead from here on
-  const int g2 = p.g2, RW2 = D * D * g2 * L, Bs2 = mk * RW2, QW2 = D * g2;
-  double *tT = k.Z, *tNh = tT + Bs2;
-  float *tB = (float *)(tNh + (((size_t)m * m + 1) & ~(size_t)1));
-  const float *tPl = k.sPl2;
-  const double *tNg = k.dNg2;
   YSTAMP(10);
   if (p.Nh_new) {
     // T2[h_, (d, s'')] = sum_h' Nh[h_, h'] Cb[h', (d, s'')]
     const int DM = D * mk;
-#ifdef TNML_EXP_FINE_STAMPS
-    // experiment: the same product twice through the same code -- the second pass finds its instructions in the cache
-    for (int rep = 0; rep < (p.stamps ? 2 : 1); ++rep) {
-      mm_lds(1, h, DM, h, k.dNh, 0, h, 1, k.sCb, 0, DM, 1, [&](int, int i, int j, double v) { k.dT2[i * DM + j] = v; });
-      if (rep == 0) { YSTAMP(8); }
-      lds_barrier();
-    }
-    YSTAMP(11);
-#else
     mm_lds(1, h, DM, h, k.dNh, 0, h, 1, k.sCb, 0, DM, 1, [&](int, int i, int j, double v) { k.dT2[i * DM + j] = v; });
+    YSTAMP(11);
     lds_barrier();
-#endif
     // Nh_new[s', s''] = sum_{(h_, d)} Cb[(h_, d), s'] T2[(h_, d), s'']
     mm_lds(1, mk, mk, h * D, k.sCb, 0, 1, mk, k.dT2, 0, mk, 1,
-           [&](int, int i, int j, double v) { p.Nh_new[i * mk + j] = v; if (p.tail_prep) tNh[i * mk + j] = v; });
+           [&](int, int i, int j, double v) { p.Nh_new[i * mk + j] = v; });
   }
-  // ---- phase 12: merged tensor and L2 term of the NEXT step (the arithmetic of prep_slice_block, small_gemm_device.h) ------
   YSTAMP(12);
-  if (p.tail_prep) {
-    lds_barrier();
-    mm_lds(L, mk * D, QW2, g, k.sLab2, 1, g * L, L, tPl, 0, QW2, 1,
-           [&](int l, int i, int j, double v) {
-             const float fv = (float)v;
-             tB[(i * QW2 + j) * L + l] = fv;
-             p.prepB[(size_t)(i * QW2 + j) * L + l] = fv;
-           });
-    YSTAMP(13);
-    if (p.l2_flag) {
-      lds_barrier();
-      mm_lds(1, mk, RW2, mk, tNh, 0, 1, mk, tB, 0, RW2, 1, [&](int, int i, int j, double v) { tT[i * RW2 + j] = v; });
-      YSTAMP(14);
-      lds_barrier();
-      mm_lds(L, Bs2 / (g2 * L), g2, g2, tT, 1, g2 * L, L, tNg, 0, g2, 1,
-             [&](int l, int i, int j, double v) { p.prepG[(size_t)(i * g2 + j) * L + l] = v; });
-      YSTAMP(15);
-    }
-  }
 
   if (p.stamps && tid == 0) {
     // diagnostic stamps: shader cycles before / in / after the Jacobi loop and the 100 MHz real-time

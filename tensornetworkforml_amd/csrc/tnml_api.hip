@@ -102,12 +102,9 @@ struct tnml_ctx {
   unsigned *sync = nullptr;
   // pipelined step (wide_pipe_device.h): partial / group / reduced pre-gradients, arrival counters, B_new flag
   bool pipe_enabled = true;                  // tnml_set_step_pipeline
-  bool tail_prep = false;                    // workgroup 0 prepares the next step's merged tensor / L2 term at the end of its launch
   float *zslabs = nullptr, *gslabs = nullptr, *zred = nullptr;
   unsigned *pipe_cnt = nullptr;              // [0..15] group counters, [16] top counter, [17] flag
   int zstride = 0, pipe_nwide = 0, pipe_tpw = 1, pipe_ngroups = 0;
-  bool prep_valid = false;                   // prepB / prepG hold the merged tensor and L2 term of relative step prep_k (tail of the previous launch)
-  int prep_k = -1, prep_left = 0, prep_l2 = 0;
   bool Z_valid = false;                      // zred holds the pre-gradient of relative step Z_k of a sweep in direction Z_left
   int Z_k = -1, Z_left = 0, Z_act = 0, Z_loss = 0;
   float Z_T = 0.f;
@@ -359,7 +356,6 @@ extern "C" int tnml_set_cores(tnml_ctx *c, const float *flat, size_t n_floats, c
   c->f_current = false;
   c->Bnew_valid = false;
   c->Z_valid = false;
-  c->prep_valid = false;
   return TNML_OK;
 }
 
@@ -406,7 +402,6 @@ extern "C" int tnml_scale_cores(tnml_ctx *c, double factor) {
   c->f_current = false;
   c->Bnew_valid = false;
   c->Z_valid = false;
-  c->prep_valid = false;
   return TNML_OK;
 }
 
@@ -724,7 +719,10 @@ static int narrow_path(const tnml_ctx *c, int h, int g, int s, int L, int m) {
 
 static int run_narrow(tnml_ctx *c, NarrowParams &n, int path) {
   if (path == 0) {
-    launch_narrow(n, narrow_lds_bytes(n.h, n.g, n.s, n.L, n.m), c->stream);
+    size_t lds = narrow_lds_bytes(n.h, n.g, n.s, n.L, n.m);
+    if (n.fused && !n.prep_ready) lds = std::max(lds, prep_slice_lds_bytes(n.h, n.g, n.s, n.L));   // slice workgroups ride along
+    if (lds > 160 * 1024) return fail(TNML_ERR_ARG, "internal: update launch needs %zu bytes of LDS", lds);
+    launch_narrow(n, lds, c->stream);
     return TNML_OK;
   }
   int rc = ensure_big(c);
@@ -969,6 +967,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     n.counters = c->counters;
     // ---- pipelined step: ONE launch (update + SVD of step k next to the batch-side work of step k+1) ----------------
     bool pipe = c->pipe_enabled && fuse_ok && npath == 0 && mode == 0 && !Bdirect_dev;
+    if (pipe && prep_slice_lds_bytes(h, g, s, L) > 160 * 1024) pipe = false;      // the slice workgroups of the launch must fit too
     WidePipeParams wp{}, wpro{};
     bool need_prologue = false;
     if (pipe) {
@@ -998,42 +997,19 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
         if (c->comm) NCCL_TRY(ncclAllReduce(c->zred, c->zred, wpro.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
         if (wpro.do_f) c->f_current = true;
       }
-      // merged tensor / L2 term of this step: from the tail of the previous launch if it prepared them, else from the
-      // slice workgroups this launch carries
-      const bool have_prep = c->prep_valid && c->prep_k == k && c->prep_left == left_dir && c->prep_l2 == (l2_flag ? 1 : 0);
-      c->prep_valid = false;
+      // merged tensor / L2 term of this step: from the slice workgroups this launch carries (a slice of more than 8 rows is
+      // cut into two row parts: twice the workgroups, half the dependent tiles in each).  (Measured, round 2: preparing them
+      // at the end of the PREVIOUS launch inside workgroup 0 cost it 23 k cycles and saved 16 k of waiting -- removed.)
       n.fused = 1; n.nred = 0; n.sync = c->sync; n.red_out = nullptr;
-      n.prep_ready = have_prep ? 1 : 0;
-      // (a slice of more than 8 rows is cut into two row parts: twice the workgroups, half the dependent tiles in each)
-      n.wait_count = have_prep ? 0 : kD * kD * (h > 8 ? 2 : 1);
-      // ... and this launch's tail prepares the next step's, when that step exists and will run pipelined in LDS
-      // (measured, round 2: the three products of that preparation cost workgroup 0 23 k cycles at the end of its launch and
-      // save it 16 k cycles of waiting for the slice workgroups at the start of the next: off by default)
-      if (wp.do_z && c->tail_prep) {
-        const int p2 = left_dir ? p - 1 : p + 1;
-        const int g2 = wp.gn;
-        const int m2 = tnml_trunc_rank(trunc_policy, left_dir, p2, N, left_dir ? g2 : m, D, left_dir ? m : g2, L, c->Mpol);
-        const size_t bs2 = (size_t)m * D * D * g2 * L;
-        if (m2 > 0 && bs2 <= c->bmax && narrow_path(c, m, g2, g, L, m2) == 0 &&
-            narrow_lds_bytes(h, g, s, L, m, g2) <= 160 * 1024) {
-          n.tail_prep = 1; n.g2 = g2;
-          const int site2 = left_dir ? p - 1 : p + 2;              // relative site k+2
-          n.pl2.base = c->core_slot(site2); n.pl2.n_in = g; n.pl2.n_out = g2;
-          if (!left_dir) { n.pl2.s_in = D * g2; n.pl2.s_d = g2; n.pl2.s_out = 1; }
-          else { n.pl2.s_in = 1; n.pl2.s_d = g; n.pl2.s_out = D * g; }
-          const int as2 = left_dir ? p - 2 : p + 3;
-          n.Ng2 = (l2_flag && as2 >= 0 && as2 <= N - 1) ? c->norm_slot(nahe, as2) : nullptr;
-          c->prep_valid = true; c->prep_k = k + 1; c->prep_left = left_dir; c->prep_l2 = l2_flag ? 1 : 0;
-        }
-      }
+      n.prep_ready = 0;
+      n.wait_count = kD * kD * (h > 8 ? 2 : 1);
       n.pipe = 1; n.z_first = (k == 0); n.z_rows = wp.hprev * D;
       n.zsize = (k == 0 ? 1 : n.z_rows) * D * D * g * L;
       n.zred = c->zred; n.red = c->zred; n.zcore = wp.ext_core;
       n.flag = c->pipe_cnt + 17; n.token = ++c->token;
       wp.token = n.token;
       wp.wg0 = 1 + n.wait_count;
-      size_t lds = std::max(narrow_lds_bytes(h, g, s, L, m, n.tail_prep ? n.g2 : 0), wide_pipe_lds_bytes(wp));
-      if (!have_prep) lds = std::max(lds, prep_slice_lds_bytes(h, g, s, L));
+      const size_t lds = std::max(std::max(narrow_lds_bytes(h, g, s, L, m), wide_pipe_lds_bytes(wp)), prep_slice_lds_bytes(h, g, s, L));
       if (lds > 160 * 1024) return fail(TNML_ERR_ARG, "internal: pipelined step needs %zu bytes of LDS", lds);
       prof_begin(c);
       launch_step_pipe(n, wp, lds, c->stream);
@@ -1043,7 +1019,6 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       c->Z_valid = wp.do_z != 0; c->Z_k = k + 1; c->Z_left = left_dir; c->Z_act = act_fn; c->Z_loss = loss_fn; c->Z_T = T;
     } else {
       c->Z_valid = false;
-      c->prep_valid = false;
       // ---- wide kernel -----------------------------------------------------------------------
       WideParams w{};
       w.b = c->b; w.b_pad = c->b_pad; w.L = L;
@@ -1090,10 +1065,15 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       if (!launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream, &prep_done))
         return fail(TNML_ERR_ARG, "step at sites (%d,%d): a 32-sample tile of this bond dimension does not fit the batch kernels' LDS", p, p + 1);
       n.prep_ready = prep_done ? 1 : 0;
+      // slices the batch launch could not host would ride in the update launch -- unless they do not fit a workgroup's LDS
+      // either (bond 64 next to a chain end at three labels): then the update workgroup forms B and Ln.B.Rn itself, which
+      // the launch does only un-fused (separate reduction)
+      bool fused_now = fused;
+      if (fused_now && !prep_done && prep_slice_lds_bytes(h, g, s, L) > 160 * 1024) { fused_now = false; n.fused = 0; n.nred = 0; }
       if (n.fused) n.wait_count = n.nred + (n.prep_ready ? 0 : kD * kD);
       prof_end(c, 1);
       // ---- reduce (+ all-reduce over the batch shards) -----------------------------------------
-      if (!fused) {
+      if (!fused_now) {
         prof_begin(c);
         launch_reduce(c->slabs, nblk, c->slab_stride, (int)bsize + kMetricSlots, c->red, c->stream);
         prof_end(c, 2);
@@ -1102,7 +1082,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       prof_begin(c);
       { int rc = run_narrow(c, n, npath); if (rc) return rc; }
       prof_end(c, 3);
-      c->sweep_launches += (fused ? 2 : 3) + (npath == 1 ? 11 : 0);
+      c->sweep_launches += (fused_now ? 2 : 3) + (npath == 1 ? 11 : 0);
       c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
       if (mode == 1) {
         // the behind environment list grew (as update_B does, Network_class.py:637-652); nothing else changes
@@ -1256,9 +1236,9 @@ extern "C" int tnml_l2_term(tnml_ctx *c, const float *B_canon, int left_dir, flo
   const bool dbg_was = c->debug;
   c->debug = true;
   size_t nn = 0;
-  double sc[128];
+  double sc[kDbgScalars];
   rc = tnml_get_step_debug(c, TNML_DBG_L2_GRAD, grad_canon, capacity, &nn);
-  if (!rc) rc = tnml_get_step_debug(c, TNML_DBG_L2, sc, 128, &nn);
+  if (!rc) rc = tnml_get_step_debug(c, TNML_DBG_L2, sc, kDbgScalars, &nn);
   c->debug = dbg_was;
   if (rc) return rc;
   *loss = sc[0];
@@ -1345,7 +1325,6 @@ extern "C" int tnml_set_step_pipeline(tnml_ctx *c, int on) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   c->pipe_enabled = on != 0;
   c->Z_valid = false;
-  c->prep_valid = false;
   return TNML_OK;
 }
 

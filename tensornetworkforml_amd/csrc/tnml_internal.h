@@ -115,12 +115,6 @@ struct NarrowParams {
   CoreView zcore;          // A_{k-1}(h_{k-1}, d, h_k)
   unsigned *flag;          // if set: B_new is stored with agent-scope stores and `token` is written here afterwards
   unsigned token;
-  // tail of a pipelined launch: merged tensor and L2 term of the NEXT step (h2 = kept rank, shared bond = g, ahead bond g2)
-  // from the label core this step just produced -- the next launch then starts with prep_ready and no slice helpers
-  int tail_prep;
-  int g2;
-  CoreView pl2;            // plain core of relative site k+2: A(g, d, g2)
-  const double *Ng2;       // ahead norm environment of step k+1 (g2 x g2) or nullptr
 };
 
 struct NormChainSite {
@@ -169,7 +163,7 @@ size_t big_jacobi_lds_bytes(int n);
 // false: a launch of the path was illegal or (check) failed; big_launch_error() names it
 bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check);
 const char *big_launch_error();
-size_t narrow_lds_bytes(int h, int g, int s, int L, int m, int g2 = 0);   // g2 > 0: room for the tail preparation of the next step
+size_t narrow_lds_bytes(int h, int g, int s, int L, int m);
 void launch_norm_chain(const NormChainSite *sites_dev, int n_sites, const float *cores, double *env_base,
                        int Mmax, hipStream_t st);
 void launch_scale(float *p, size_t n, float factor, hipStream_t st);

@@ -417,5 +417,5 @@ def test_accuracy_parity_n196_fixed_bond20():
         held.append((acc_d, acc_o))
     ctx.close()
     print('N=196 fixed bond 20: worst per-step training accuracy gap %.4f; held-out (device, oracle) per sweep:' % worst_step, held)
-    assert worst_step <= 0.005
+    assert worst_step <= 0.005 + 1e-6      # one sample of the 200-sample batch is exactly 0.5 % (float32 metric)
     assert max(abs(a - o) for a, o in held) <= 0.005
