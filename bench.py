@@ -150,6 +150,7 @@ def main():
     ap.add_argument('--no-cold', action='store_true', help='skip the re-initialised (cold start) passes')
     ap.add_argument('--no-resident', action='store_true', help='skip the secondary single-resident-batch measurement')
     ap.add_argument('--classic', action='store_true', help='classic launch sequence instead of the pipelined single-launch step')
+    ap.add_argument('--pipe-tiles', type=int, default=0, help='sample tiles per batch-side workgroup on steps with a long SVD (tnml_set_step_pipeline(ctx, n), n >= 2)')
     ap.add_argument('--sync-interval', type=int, default=0, help='drain the stream every so many sweep steps (runs under rocprofv3 --pmc)')
     ap.add_argument('--check-launches', action='store_true', help='read the launch status back after every kernel launch')
     args = ap.parse_args()
@@ -179,6 +180,8 @@ def main():
         ctx.debug_enable(4)
     if args.classic:
         ctx.set_step_pipeline(False)
+    elif args.pipe_tiles >= 2:
+        ctx.set_step_pipeline(args.pipe_tiles)
 
     nb = max(1, min(args.batches, 8))
     batches = [synth(N, b, L, 1234 + 97 * k + rank) for k in range(nb)]     # every rank owns different shards

@@ -165,7 +165,9 @@ int tnml_set_svd_stop(tnml_ctx *ctx, double stop2);
 /* A sweep step is ONE launch by default: workgroup 0 updates and splits the merged tensor of step k while the other
  * workgroups of the same launch form f of step k and the batch-summed pre-gradient of step k+1.
  * on = 0 restores the classic sequence (batch kernel -> [reduction] -> update/SVD kernel), which is also what steps
- * whose merged tensor does not fit one workgroup's LDS take.  Results agree to float32 rounding. */
+ * whose merged tensor does not fit one workgroup's LDS take.  Results agree to float32 rounding.
+ * on >= 2: number of 32-sample tiles a batch-side workgroup accumulates before it writes its partial pre-gradient on steps
+ * whose SVD is long enough to hide that (short side >= 32); on = 1 means the default, 2. */
 int tnml_set_step_pipeline(tnml_ctx *ctx, int on);
 
 /* tnml_sweep enqueues every launch of its n_steps steps without waiting (2 - 14 launches per step).  A profiler that

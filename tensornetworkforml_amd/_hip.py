@@ -330,7 +330,7 @@ class Context:
 
     def set_step_pipeline(self, on):
         """True (default): one launch per sweep step (pipelined); False: the classic launch sequence."""
-        _chk(lib().tnml_set_step_pipeline(self._h, int(bool(on))))
+        _chk(lib().tnml_set_step_pipeline(self._h, int(on)))
 
     def set_sync_interval(self, n_steps):
         """Drain the stream every n_steps sweep steps (0: never); for runs under a dispatch-intercepting profiler."""

@@ -102,6 +102,7 @@ struct tnml_ctx {
   unsigned *sync = nullptr;
   // pipelined step (wide_pipe_device.h): partial / group / reduced pre-gradients, arrival counters, B_new flag
   bool pipe_enabled = true;                  // tnml_set_step_pipeline
+  int pipe_tiles = 2;                        // sample tiles per batch-side workgroup where the SVD is long enough to hide them
   float *zslabs = nullptr, *gslabs = nullptr, *zred = nullptr;
   unsigned *pipe_cnt = nullptr;              // [0..15] group counters, [16] top counter, [17] flag
   int zstride = 0, pipe_nwide = 0, pipe_tpw = 1, pipe_ngroups = 0;
@@ -975,6 +976,13 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       wp.do_ext = k >= 1; wp.do_f = 1; wp.wait_flag = 1;
       wp.do_z = (k + 1 <= N - 2);
       if (wp.do_z && !wide_pipe_fits(c, wp)) wp.do_z = 0;            // the next step will start from its own prologue
+      if (wp.do_z && c->pipe_tiles > wp.tiles_per_wg && nn >= 32) {
+        // the SVD of this step is long (short side >= 32): a batch-side workgroup accumulates several sample tiles in
+        // registers before it writes its partial pre-gradient -- proportionally fewer partial tensors to write and re-read
+        wp.tiles_per_wg = c->pipe_tiles;
+        wp.nwide = (wp.ntiles + wp.tiles_per_wg - 1) / wp.tiles_per_wg;
+        wp.ngroups = (wp.nwide + kPipeGroupMax - 1) / kPipeGroupMax;
+      }
       if (!wide_pipe_fits(c, wp)) pipe = false;
       const bool zok = c->Z_valid && c->Z_k == k && c->Z_left == left_dir && c->Z_act == act_fn && c->Z_loss == loss_fn && c->Z_T == T;
       if (pipe && !zok) {
@@ -1324,6 +1332,7 @@ extern "C" int tnml_set_narrow_path(tnml_ctx *c, int force_large) {
 extern "C" int tnml_set_step_pipeline(tnml_ctx *c, int on) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   c->pipe_enabled = on != 0;
+  c->pipe_tiles = on >= 2 ? on : (on == 1 ? 2 : 1);
   c->Z_valid = false;
   return TNML_OK;
 }

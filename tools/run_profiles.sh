@@ -8,12 +8,14 @@
 CFG=${1:-c3}
 shift
 EXTRA="$@"
+# kernel-trace pass = the driver's command; c5 (0.3 s per pass, 14 launches per step) with 6 / 2 passes
+if [ "$CFG" = c5 ]; then KT="--steps 6 --warmup 2"; else KT="--steps 20 --warmup 5"; fi
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_kt_$CFG $OUT/prof_fetch_$CFG $OUT/prof_write_$CFG $OUT/prof_mfma_$CFG
 SHORT="--config $CFG --steps 2 --warmup 1 --cpu-steps 0 --no-kernel-profile --no-cold --no-resident --sync-interval 4 $EXTRA"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt_$CFG -- python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 5 --cpu-steps 0 $EXTRA > $OUT/prof_kt_$CFG.json 2> $OUT/prof_kt_$CFG.err && \
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt_$CFG -- python3 $ROOT/bench.py --config $CFG $KT --cpu-steps 0 $EXTRA > $OUT/prof_kt_$CFG.json 2> $OUT/prof_kt_$CFG.err && \
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch_$CFG -- python3 $ROOT/bench.py $SHORT > /dev/null 2> $OUT/prof_fetch_$CFG.err && \
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write_$CFG -- python3 $ROOT/bench.py $SHORT > /dev/null 2> $OUT/prof_write_$CFG.err && \
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $OUT/prof_mfma_$CFG -- python3 $ROOT/bench.py $SHORT > /dev/null 2> $OUT/prof_mfma_$CFG.err
