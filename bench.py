@@ -243,8 +243,10 @@ def main():
         _, n_steps_pipe = ctx.profile_get(5)
         drain_whole()
         sw_tot, n_svd, rounds_tot = ctx.svd_stats(reset=True)
+        chol = ctx.cholesky_steps
         return dict(dt=dt, sweep_ms=sweep_ms, launches=n_launch, pipe_steps=n_steps_pipe, counters=cnt,
-                    sweeps_per_svd=sw_tot / max(n_svd, 1), rounds_per_svd=rounds_tot / max(n_svd, 1))
+                    sweeps_per_svd=sw_tot / max(n_svd, 1), rounds_per_svd=rounds_tot / max(n_svd, 1),
+                    cholesky_fraction=chol / max(n_svd, 1))
 
     ctx.profile_reset()
     ctx.profile_enable(2)
@@ -313,6 +315,7 @@ def main():
         'counters': main_run['counters'],
         # the SVD is iterative: how much work the timed passes actually contained
         'jacobi': {'sweeps_per_svd': main_run['sweeps_per_svd'], 'rounds_per_svd': main_run['rounds_per_svd'],
+                   'cholesky_fraction': main_run['cholesky_fraction'],
                    'svd_stop2': args.svd_stop if args.svd_stop is not None else 1e-6},
     }
 
@@ -374,7 +377,7 @@ def main():
                       hp['T'], hp['trunc'], want_metrics=False, want_f=False)
             ctx.debug_enable(0 if not args.check_launches else 4)
             if sc[10] > 1:
-                rounds = sc[9] * (sc[10] - 1)
+                rounds = sc[55] if len(sc) > 55 and sc[55] > 0 else sc[9] * (sc[10] - 1)      # rounds actually run
                 out['critical_path'] = {'what': 'workgroup 0 of one mid-chain step (shader cycles from s_memtime stamps)',
                                         'cycles_before_svd': sc[5], 'cycles_jacobi': sc[6], 'cycles_after_svd': sc[7],
                                         'jacobi_sweeps': sc[9], 'matrix_side': sc[10], 'rounds': rounds,
@@ -402,7 +405,7 @@ def main():
             one_pass(rotate=False)
         r = timed(args.steps, rotate=False)
         out['resident_batch'] = {'value': (1 if strong else world) * sweep_steps / r['dt'], 'unit': 'sweep-steps/s',
-                                 'jacobi_sweeps_per_svd': r['sweeps_per_svd']}
+                                 'jacobi_sweeps_per_svd': r['sweeps_per_svd'], 'cholesky_fraction': r['cholesky_fraction']}
 
     if not args.no_cold:
         # "cold" passes: network re-initialised (random cores, calibrated) and swept twice -- the regime of the first
@@ -411,7 +414,7 @@ def main():
         init_network()
         r = timed(2)
         out['cold_start'] = {'value': (1 if strong else world) * 2 * (N - 1) / r['dt'], 'unit': 'sweep-steps/s', 'passes': 2,
-                             'jacobi_sweeps_per_svd': r['sweeps_per_svd']}
+                             'jacobi_sweeps_per_svd': r['sweeps_per_svd'], 'cholesky_fraction': r['cholesky_fraction']}
 
     if rank == 0 and args.cpu_steps > 0:
         rate, t_fwd, t_step, st, fcpu, Xc, y1h = cpu_baseline(N, M, D, L, b, args.cpu_steps, 1234)

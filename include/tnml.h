@@ -228,8 +228,8 @@ int tnml_profile_reset(tnml_ctx *ctx);
  *           device ms inside the sweeps (0 unless tnml_profile_enable(ctx, 2) was on; read it through tnml_profile_get(4) first)} */
 int tnml_get_counters(tnml_ctx *ctx, double *out8);
 /* always-on counters of the Jacobi SVD since the last reset:
- *   out3 = {total sweeps, number of SVDs, total rounds (one barrier each)} */
-int tnml_svd_stats(tnml_ctx *ctx, int reset, double *out3);
+ *   out4 = {total sweeps, number of SVDs, total rounds (one barrier each), SVDs that took the pivoted-Cholesky step first} */
+int tnml_svd_stats(tnml_ctx *ctx, int reset, double *out4);
 
 /* Host-side planning helper, exported so that CPU tests can check the bond bookkeeping without a
  * GPU: truncation rank kept by tensor_svd (Network_class.py:894-945) for a step on sites

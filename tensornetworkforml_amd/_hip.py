@@ -375,9 +375,10 @@ class Context:
         _chk(lib().tnml_profile_reset(self._h))
 
     def svd_stats(self, reset=False):
-        """(total Jacobi sweeps, SVDs, total rounds) since the last reset."""
-        out = (C.c_double * 3)()
+        """(total Jacobi sweeps, SVDs, total rounds) since the last reset; `cholesky_steps` holds the fourth counter."""
+        out = (C.c_double * 4)()
         _chk(lib().tnml_svd_stats(self._h, int(bool(reset)), out))
+        self.cholesky_steps = out[3]
         return out[0], out[1], out[2]
 
     def counters(self):

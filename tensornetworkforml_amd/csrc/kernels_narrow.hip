@@ -193,6 +193,8 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   __builtin_assume(p.L >= 1 && p.L <= 2048 && p.bsize >= 1 && p.bsize <= 8192);
   const NarrowCarve k = narrow_carve(smem_raw, p.h, p.g, p.s, p.L, p.m);
   const int tid = threadIdx.x, NT = kNarrowThreads;
+  // the wave index as a scalar: loops and role tests built on it become SALU control flow instead of EXEC-mask bookkeeping
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = kD, h = p.h, g = p.g, s = p.s, L = p.L, m = p.m, Bs = p.bsize;
   // reduced gradient + metric tail: written by other workgroups of THIS launch when fused -> coherent loads
   auto ldred = [&](int e) -> float {
@@ -506,7 +508,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       if (p.dbg) { double *dd = p.dbg + 2 * (size_t)Bs + e; dd[0] = v.x; dd[1] = v.y; dd[2] = v.z; dd[3] = v.w; }
     }
   } else {
-    for (int row = tid >> 6; row < r; row += NT >> 6)       // rows over waves, columns over lanes
+    for (int row = wave_u; row < r; row += NT >> 6)       // rows over waves, columns over lanes
       for (int x = tid & 63; x < c; x += 64) {
         const int e = row * c + x;
         const float v = (float)((double)k.fB[e] + factor * k.dG[e]);
@@ -555,7 +557,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   double g_tr = 0.0, g_dg2 = 0.0, g_off2 = 0.0;
   {
     double *P0 = G0, *P1 = G1, *P2 = V0, *P3 = k.Z + 3 * ne * ne;
-    const int lane = tid & 63, wave = tid >> 6, rr = lane & 15, qq = lane >> 4;
+    const int lane = tid & 63, wave = wave_u, rr = lane & 15, qq = lane >> 4;
     const int tm = (n + 15) >> 4;
     const int kchunk = ((len + kGramSplit - 1) / kGramSplit + 3) & ~3;       // multiple of the MFMA k = 4
     // (tile, slice) items dealt round-robin to the waves: nested counters, no integer division (a per-lane division costs
@@ -567,7 +569,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 #endif
     // this wave's (tile, slice) items, decoded from a wave-uniform index with scalar instructions only (the wave index is
     // made uniform for the compiler by v_readfirstlane); W(x, kk) = Wb[x * rs + kk * cs]
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wave_s = wave;
     const float *Wb = short_rows ? k.fBp : k.fB;
     const int rs = short_rows ? c + 1 : 1, cs = short_rows ? 1 : c;
     const int nitems = ((tm * (tm + 1)) >> 1) * kGramSplit;
@@ -624,7 +626,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     // sum of the slices, in slice order, written to both triangles (exact symmetry; tiles below the diagonal were never
     // written, and inside a diagonal tile only i <= j is read).  Rows over waves, columns over lanes: no division.  The
     // same pass collects trace, sum of squared diagonal and of squared off-diagonal entries.
-    for (int i = tid >> 6; i < ne; i += NT >> 6)
+    for (int i = wave_u; i < ne; i += NT >> 6)
       for (int j = tid & 63; j < ne; j += 64)
         if (i <= j) {
           const int e = i * ne + j;
@@ -657,7 +659,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   const double tr = g_tr, off2 = g_off2;
   const int sc_exp = (tr > 0.0 && isfinite(tr)) ? __builtin_amdgcn_frexp_exp(tr) : 0;
   const bool chol_possible = p.chol_thr > 0.0 && n > 4;   // tiny matrices (chain ends, reference policy): never worth it
-  for (int i = tid >> 6; i < ne; i += NT >> 6)
+  for (int i = wave_u; i < ne; i += NT >> 6)
     for (int j = tid & 63; j < ne; j += 64) G0[i * ne + j] = __builtin_amdgcn_ldexp(G0[i * ne + j], -sc_exp);
   lds_barrier();
 
@@ -776,8 +778,12 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   const int NVW = (np + vr * gpw - 1) / (vr * gpw);      // V waves
   // worker waves = every wave but wave 0 (the parameter wave).  (Measured, round 2: once the parameter chain runs in float32
   // the round is bound by the float64 issue rate of the working waves; keeping wave 0's SIMD free of them does not pay.)
-  const int nwork = (NT >> 6) - 1, wrank = (tid >> 6) - 1;
-  const int NW = (nwork - NVW) * 64;                     // threads that own G items
+  const int nwork = (NT >> 6) - 1, wrank = wave_u - 1;
+  // threads that own G items: as few waves as hold them at one item per lane (np(np+1)/2 = 210 items at n = 40: 4 waves, not
+  // the 8 that are left) -- a round is bound by the float64 issue slots the worker waves share per SIMD, and a wave costs
+  // its slots whatever the number of active lanes
+  const int nGw = min(nwork - NVW, (np * (np + 1) / 2 + 63) / 64);
+  const int NW = nGw * 64;
   const int gtid = (wrank - NVW) * 64 + (tid & 63);      // index among them (negative: not a G wave)
   const int vlane = tid & 63, vgrp = vlane / np, vQ = vlane - vgrp * np;
   const bool isVwave = wrank >= 0 && wrank < NVW;
@@ -800,7 +806,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 #pragma unroll
   for (int u = 0; u < MAXI; ++u) {
     const int it = gtid + u * NW;
-    itValid[u] = wrank >= NVW && it < nG;
+    itValid[u] = wrank >= NVW && gtid < NW && it < nG;
     int P = 0, Q = 0;
     if (itValid[u]) {                         // it-th pair (P <= Q) in row-major order of the upper triangle
       int rem = it;
@@ -827,7 +833,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     // (kKeptFrac * m-th largest diagonal entry)^2, block-wide; ends with a barrier
     const int i = tid & 63;
     const double li = i < n ? G[i * ne + i] : 0.0;
-    for (int j = tid >> 6; j < n; j += NT >> 6) {         // one wave per entry, ballot = rank (n <= 64)
+    for (int j = wave_u; j < n; j += NT >> 6) {         // one wave per entry, ballot = rank (n <= 64)
       const double lj = G[j * ne + j];
       const int rank = __popcll(__ballot(i < n && ((li > lj) || (li == lj && i < j))));
       if (i == 0 && rank == m - 1) k.dRed[60] = lj;
@@ -989,8 +995,14 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     // about a third of a sweep per decomposition once the chain has settled).
     for (; sweeps < kJacobiMaxSweeps && !converged; ++sweeps) {
       for (int rnd = 0; rnd < ne - 1; ++rnd) {
+#ifdef TNML_EXP_FINE_STAMPS
         jacobi_round(p.stamps && tid == 0 && sweeps == 0 && rnd == 7, true, true, true, sweeps == 0 && rnd == 7);
-        if (round_idx - last_big1 >= ne - 1) { converged = 1; break; }      // block-uniform
+#else
+        jacobi_round(false, true, true, true);
+#endif
+        // block-uniform, and told so: the flag word comes out of LDS (a vector register), and a loop exit the compiler has
+        // to treat as divergent wraps every round in EXEC-mask bookkeeping
+        if (round_idx - __builtin_amdgcn_readfirstlane(last_big1) >= ne - 1) { converged = 1; break; }
       }
       if (!converged) kept2 = kept_scale(Gc);
     }
@@ -1026,7 +1038,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     V = Gn;
     lds_barrier();
   }
-  for (int j = tid >> 6; j < n; j += NT >> 6) {           // one wave per entry: lane i votes "i sorts before j" (n <= 64)
+  for (int j = wave_u; j < n; j += NT >> 6) {           // one wave per entry: lane i votes "i sorts before j" (n <= 64)
     const int i = tid & 63;
     const double lj = k.dLam[j];
     const double li = i < n ? k.dLam[i] : 0.0;
@@ -1041,6 +1053,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       atomicAdd(p.counters, (unsigned long long)sweeps);                 // started sweeps (the last one may be partial)
       atomicAdd(p.counters + 1, 1ull);
       atomicAdd(p.counters + 2, (unsigned long long)round_idx);
+      if (use_chol) atomicAdd(p.counters + 3, 1ull);
     }
     if (!converged) atomicOr(p.status, 2);
     if (p.dbg) {
@@ -1086,7 +1099,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   lds_barrier();
   YSTAMP(6);
   // short-side factor: q_j * sigma_j^(1/2)   (rows kk over waves, kept columns over lanes: no divisions)
-  for (int kk = tid >> 6; kk < n; kk += NT >> 6)
+  for (int kk = wave_u; kk < n; kk += NT >> 6)
    for (int sp = tid & 63; sp < mk; sp += 64) {
     const int j = k.sOrd[sp];
     const float v = (float)(V[kk * ne + j] * k.dSq[sp]);
@@ -1144,6 +1157,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     const unsigned long long t_c3 = __builtin_amdgcn_s_memtime(), t_r3 = __builtin_amdgcn_s_memrealtime();
     p.stamps[0] = (double)(t_c1 - t_c0); p.stamps[1] = (double)(t_c2 - t_c1); p.stamps[2] = (double)(t_c3 - t_c2);
     p.stamps[3] = (double)(t_r3 - t_r0); p.stamps[4] = (double)sweeps; p.stamps[5] = (double)n;
+    p.stamps[50] = (double)round_idx;                 // rounds actually run (the sliding window stops inside a sweep)
     for (int i = 0; i < 5; ++i) p.stamps[9 + i] = (double)(t_p[i] - (i ? t_p[i - 1] : t_c0));
 #ifdef TNML_EXP_FINE_STAMPS
     p.stamps[34] = (double)(t_x[0] - t_p[2]); p.stamps[35] = (double)(t_x[1] - t_x[0]); p.stamps[36] = (double)(t_x[2] - t_x[1]);

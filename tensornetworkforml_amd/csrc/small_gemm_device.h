@@ -22,7 +22,8 @@ __device__ inline void small_gemm_f64(int nbatch, int M, int N, int K, FA loadA,
   // C_b[M x N] = A_b[M x K] . B_b[K x N] for b < nbatch; loadA(b, i, k), loadB(b, k, j),
   // store(b, i, j, value) must be LINEAR index maps (no run-time divisions: they are evaluated per
   // element); a composite row index such as (site index, label) is expressed through the batch.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform for the compiler: scalar tile bookkeeping
   const int tn = (N + 15) >> 4, tm = (M + 15) >> 4, per = tm * tn, ntiles = nbatch * per;
   const int r = lane & 15, q = lane >> 4;
   for (int t = wave; t < ntiles; t += nw) {

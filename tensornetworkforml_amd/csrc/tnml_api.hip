@@ -1457,13 +1457,14 @@ extern "C" int tnml_get_counters(tnml_ctx *c, double *out8) {
   return TNML_OK;
 }
 
-extern "C" int tnml_svd_stats(tnml_ctx *c, int reset, double *out3) {
+extern "C" int tnml_svd_stats(tnml_ctx *c, int reset, double *out4) {
+  double *out3 = out4;
   if (!c || !out3) return fail(TNML_ERR_ARG, "NULL argument");
   HIP_TRY(hipSetDevice(c->device));
   unsigned long long h[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  out3[0] = (double)h[0]; out3[1] = (double)h[1]; out3[2] = (double)h[2];
+  out3[0] = (double)h[0]; out3[1] = (double)h[1]; out3[2] = (double)h[2]; out4[3] = (double)h[3];
   if (reset) HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof h, c->stream));
   return TNML_OK;
 }

@@ -136,7 +136,8 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
   const WidePipeDims dm = wide_pipe_dims(p);
   const WidePipeSmem w = wide_pipe_carve(smem, p, dm);
   const int tid = threadIdx.x, NT = kPipeThreads;
-  const int lane = tid & 63, wave = tid >> 6, NWV = NT / 64;
+  const int lane = tid & 63, NWV = NT / 64;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: tile loops on it become SALU control flow
   const int r = lane & 15, q = lane >> 4;
   const int L = p.L, hj = p.hj, gj = p.gj, gn = p.gn, hprev = p.hprev;
   const int nI = dm.nI, nJ = kD * gj;

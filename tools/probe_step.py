@@ -30,7 +30,7 @@ def stamp_line(tag, sc):
     cyc = sc[5] + sc[6] + sc[7]
     print('%s: cycles pre/jacobi/post = %d / %d / %d ; kernel %.1f us ; clock %.2f GHz ; sweeps %d n %d ; %.0f cycles per round'
           % (tag, sc[5], sc[6], sc[7], sc[8] / 100.0, cyc / max(sc[8] / 100.0, 1e-9) / 1e3, sc[9], sc[10],
-             sc[6] / max(1, sc[9] * (sc[10] - 1))))
+             sc[6] / max(1, sc[55] if len(sc) > 55 and sc[55] > 0 else sc[9] * (sc[10] - 1))))
     if len(sc) > 18:
         print('   pre split: load %d / B %d / L2 %d / sums+update %d / gram %d cycles' % tuple(sc[14:19]))
     if len(sc) > 21:
