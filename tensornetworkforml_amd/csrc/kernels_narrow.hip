@@ -828,6 +828,11 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   int pa = 0, pb = 1;
   if (isParam) { pa = k.sPiInv[2 * tid]; pb = k.sPiInv[2 * tid + 1]; }
   const int pA = pa >> 1, ra = pa & 1, pB = pb >> 1, rb = pb & 1;
+  // element offsets of the parameter thread's reads, formed once: left inline they are eight 32-bit multiplies per round on
+  // the critical chain of the parameter wave (v_mul_lo_u32 issues at quarter rate)
+  const int oAd = (2 * pA) * ne + 2 * pA, oAb = (2 * pA + 1) * ne + 2 * pA + 1;
+  const int oBd = (2 * pB) * ne + 2 * pB, oBb = (2 * pB + 1) * ne + 2 * pB + 1;
+  const int oR0 = pA <= pB ? (2 * pA) * ne + 2 * pB : (2 * pB) * ne + 2 * pA, oR1 = oR0 + ne;   // stored block (min, max)
 
   auto kept_scale = [&](const double *G) -> double {
     // (kKeptFrac * m-th largest diagonal entry)^2, block-wide; ends with a barrier
@@ -870,17 +875,17 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
           // rotations, in float32 (the inputs are read as float64 and converted)
           const float2 fA = *reinterpret_cast<const float2 *>(csc + 4 * pA + 2);     // (t, c0) of pair A
           const float2 fB = *reinterpret_cast<const float2 *>(csc + 4 * pB + 2);
-          const double2 dA = *reinterpret_cast<const double2 *>(Gc + (2 * pA) * ne + 2 * pA);
-          const double bA = Gc[(2 * pA + 1) * ne + 2 * pA + 1];
-          const double2 dB = *reinterpret_cast<const double2 *>(Gc + (2 * pB) * ne + 2 * pB);
-          const double bB = Gc[(2 * pB + 1) * ne + 2 * pB + 1];
+          const double2 dA = *reinterpret_cast<const double2 *>(Gc + oAd);
+          const double bA = Gc[oAb];
+          const double2 dB = *reinterpret_cast<const double2 *>(Gc + oBd);
+          const double bB = Gc[oBb];
           double2 r0, r1;                                       // rows of block (A, B)
           if (pA < pB) {
-            r0 = *reinterpret_cast<const double2 *>(Gc + (2 * pA) * ne + 2 * pB);
-            r1 = *reinterpret_cast<const double2 *>(Gc + (2 * pA + 1) * ne + 2 * pB);
+            r0 = *reinterpret_cast<const double2 *>(Gc + oR0);
+            r1 = *reinterpret_cast<const double2 *>(Gc + oR1);
           } else if (pA > pB) {                                 // stored as (B, A): transpose
-            const double2 s0 = *reinterpret_cast<const double2 *>(Gc + (2 * pB) * ne + 2 * pA);
-            const double2 s1 = *reinterpret_cast<const double2 *>(Gc + (2 * pB + 1) * ne + 2 * pA);
+            const double2 s0 = *reinterpret_cast<const double2 *>(Gc + oR0);
+            const double2 s1 = *reinterpret_cast<const double2 *>(Gc + oR1);
             r0 = make_double2(s0.x, s1.x);
             r1 = make_double2(s0.y, s1.y);
           } else {                                              // n == 2: the pair meets itself again
