@@ -331,12 +331,15 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
           if (!itDiag[u]) Gn[itD21[u]] = n21;
           Gn[itD22[u]] = n22;
         }
-        __syncthreads();
+        // LDS-only barrier: __syncthreads() would also drain the parameter threads' stores to the rotation log (global memory,
+        // read by the next kernel) -- a memory round trip per round
+        lds_barrier();
         double *tsw = Gc; Gc = Gn; Gn = tsw;
         cur ^= 1;
         ++rounds;
         last_big1 = max(last_big1, big_slot);
-        if (rounds - last_big1 >= ne - 1) { converged = 1; break; }
+        // block-uniform, and told so (the flag word comes out of LDS): a scalar loop exit
+        if (rounds - __builtin_amdgcn_readfirstlane(last_big1) >= ne - 1) { converged = 1; break; }
       }
       if (!converged) kept2 = kept_scale(Gc);
     }
