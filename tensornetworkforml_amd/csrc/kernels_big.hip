@@ -266,13 +266,23 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
   if (n > 1) {
     kept2 = kept_scale(Gc);
     if (tid == 0) { sFlag[2] = 0; sFlag[3] = 0; }
+    // Rotation slot of pair k in dCS (4 doubles): [0] t, [1] c0 as doubles (float32-exact values), [2] the same two as a
+    // float2 for the look-ahead chain -- the scheme of the in-LDS kernel (kernels_narrow.hip phase 7, jacobi_rot_f32): the
+    // dependent chain that sets the length of a round runs in float32, the threads that APPLY a rotation refine its cosine
+    // to float64 themselves (rot_corr), and the log for the replay kernel gets the refined (c, s) off the critical path.
+    const float kept_lo = 1e-36f;
+    auto publish = [&](double *o, const RotT &r, int applied, size_t log_at) {
+      *reinterpret_cast<double2 *>(o) = make_double2((double)r.t, (double)r.c0);
+      *reinterpret_cast<float2 *>(o + 2) = make_float2(r.t, r.c0);
+      if (r.level >= 2) sFlag[2 + (applied & 1)] = applied + 1;
+      const double c = (double)r.c0 * rot_corr((double)r.t, (double)r.c0);
+      a.rotlog[log_at] = make_double2(c, c * (double)r.t);
+    };
     if (isParam) {
       const int sl = 4 * blk_index(tid, tid, np);
-      const Rot r = jacobi_rot(Gc[sl], Gc[sl + 3], Gc[sl + 1], kept2, abs2, a.stop2);
-      double *o = dCS + (cur * np + tid) * 4;
-      o[0] = r.c; o[1] = r.s; o[2] = r.t;
-      a.rotlog[tid] = make_double2(r.c, r.s);
-      if (r.level >= 2) sFlag[2] = 1;                // applied in round 0
+      const RotT r = jacobi_rot_f32((float)Gc[sl], (float)Gc[sl + 3], (float)Gc[sl + 1], fmaxf((float)kept2, kept_lo), (float)abs2,
+                                    (float)a.stop2);
+      publish(dCS + (cur * np + tid) * 4, r, 0, (size_t)tid);
     }
     __syncthreads();
     // sliding window, as in the in-LDS kernel (kernels_narrow.hip phase 7): stop as soon as ne - 1 consecutive rounds applied no
@@ -283,9 +293,10 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
         const double *csc = dCS + cur * np * 4;
         const int big_slot = sFlag[2 + (rounds & 1)];
         if (isParam) {
-          const double2 csA = *reinterpret_cast<const double2 *>(csc + 4 * pA);
-          const double2 csB = *reinterpret_cast<const double2 *>(csc + 4 * pB);
-          const double tA = csc[4 * pA + 2], tB = csc[4 * pB + 2];
+          // look-ahead: pair `tid` of the NEXT round is (a, b) in today's positions; its three elements after today's
+          // rotations, in float32
+          const float2 fA = *reinterpret_cast<const float2 *>(csc + 4 * pA + 2);     // (t, c0) of pair A
+          const float2 fB = *reinterpret_cast<const float2 *>(csc + 4 * pB + 2);
           const double2 dA = *reinterpret_cast<const double2 *>(Gc + slotAA);
           const double bA = Gc[slotAA + 3];
           const double2 dB = *reinterpret_cast<const double2 *>(Gc + slotBB);
@@ -303,30 +314,34 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
             r0 = dA;
             r1 = make_double2(dA.y, bA);
           }
-          const double na = ra ? fma(tA, dA.y, bA) : fma(-tA, dA.y, dA.x);
-          const double nb = rb ? fma(tB, dB.y, bB) : fma(-tB, dB.y, dB.x);
-          const double h0 = ra ? fma(csA.y, r0.x, csA.x * r1.x) : fma(csA.x, r0.x, -csA.y * r1.x);
-          const double h1 = ra ? fma(csA.y, r0.y, csA.x * r1.y) : fma(csA.x, r0.y, -csA.y * r1.y);
-          const double ng = rb ? fma(csB.y, h0, csB.x * h1) : fma(csB.x, h0, -csB.y * h1);
-          const Rot r = jacobi_rot(na, nb, ng, kept2, abs2, a.stop2);
-          double *o = dCS + ((cur ^ 1) * np + tid) * 4;
-          o[0] = r.c; o[1] = r.s; o[2] = r.t;
-          a.rotlog[(size_t)(rounds + 1) * np + tid] = make_double2(r.c, r.s);
-          if (r.level >= 2) sFlag[2 + ((rounds + 1) & 1)] = rounds + 2;
+          const float tA = fA.x, cA = fA.y, sA = fA.x * fA.y, tB = fB.x, cB = fB.y, sB = fB.x * fB.y;
+          const float aAx = (float)dA.x, aAy = (float)dA.y, aAb = (float)bA, aBx = (float)dB.x, aBy = (float)dB.y, aBb = (float)bB;
+          const float q0x = (float)r0.x, q0y = (float)r0.y, q1x = (float)r1.x, q1y = (float)r1.y;
+          const float na = ra ? fmaf(tA, aAy, aAb) : fmaf(-tA, aAy, aAx);
+          const float nb = rb ? fmaf(tB, aBy, aBb) : fmaf(-tB, aBy, aBx);
+          const float h0 = ra ? fmaf(sA, q0x, cA * q1x) : fmaf(cA, q0x, -sA * q1x);
+          const float h1 = ra ? fmaf(sA, q0y, cA * q1y) : fmaf(cA, q0y, -sA * q1y);
+          const float ng = rb ? fmaf(sB, h0, cB * h1) : fmaf(cB, h0, -sB * h1);
+          const RotT r = jacobi_rot_f32(na, nb, ng, fmaxf((float)kept2, kept_lo), (float)abs2, (float)a.stop2);
+          publish(dCS + ((cur ^ 1) * np + tid) * 4, r, rounds + 1, (size_t)(rounds + 1) * np + tid);
         }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
           if (!itValid[u]) continue;
-          const double2 csq = *reinterpret_cast<const double2 *>(csc + itQ[u]);
-          const double2 csp = *reinterpret_cast<const double2 *>(csc + itP[u]);
+          const double2 tq = *reinterpret_cast<const double2 *>(csc + itQ[u]);       // (t, c0) of the column pair
+          const double2 tp = *reinterpret_cast<const double2 *>(csc + itP[u]);       // ... of the row pair
           const double2 r0 = *reinterpret_cast<const double2 *>(Gc + itSrc[u]);
           double2 r1 = *reinterpret_cast<const double2 *>(Gc + itSrc[u] + 2);
           if (itDiag[u]) r1.x = r0.y;
-          const double h11 = csp.x * r0.x - csp.y * r1.x, h12 = csp.x * r0.y - csp.y * r1.y;
-          const double h21 = csp.y * r0.x + csp.x * r1.x, h22 = csp.y * r0.y + csp.x * r1.y;
-          double n11 = csq.x * h11 - csq.y * h12, n12 = csq.y * h11 + csq.x * h12;
-          double n21 = csq.x * h21 - csq.y * h22, n22 = csq.y * h21 + csq.x * h22;
-          if (itDiag[u] && csq.y != 0.0) { n12 = 0.0; n21 = 0.0; }
+          // R_P^T . blk . R_Q = cP cQ [[1, -tP], [tP, 1]] . blk . [[1, tQ], [-tQ, 1]]: the tangents act first, the product of the
+          // two refined cosines is formed meanwhile and multiplied in last
+          const double a11 = fma(-tp.x, r1.x, r0.x), a12 = fma(-tp.x, r1.y, r0.y);
+          const double a21 = fma(tp.x, r0.x, r1.x), a22 = fma(tp.x, r0.y, r1.y);
+          const double b11 = fma(-tq.x, a12, a11), b12 = fma(tq.x, a11, a12);
+          const double b21 = fma(-tq.x, a22, a21), b22 = fma(tq.x, a21, a22);
+          const double c00 = tp.y * tq.y, corr = rot_corr(tp.x, tp.y) * rot_corr(tq.x, tq.y);
+          double n11 = (b11 * c00) * corr, n12 = (b12 * c00) * corr, n21 = (b21 * c00) * corr, n22 = (b22 * c00) * corr;
+          if (itDiag[u] && tq.x != 0.0) { n12 = 0.0; n21 = 0.0; }
           Gn[itD11[u]] = n11; Gn[itD12[u]] = n12;
           if (!itDiag[u]) Gn[itD21[u]] = n21;
           Gn[itD22[u]] = n22;
