@@ -85,22 +85,26 @@ __device__ inline int mm_lds(int nbatch, int M, int N, int K, const TA *A, int a
   const int nk = (K + 3) >> 2;                         // k-steps of 4
   const bool ktail = (K & 3) != 0;                     // the last step reaches past K
   const int sa = 4 * a_ks, sb = 4 * b_ks;
-  // tiles are dealt to the waves in the order they are met; three nested counters instead of t / per, t % tn: a wave-uniform
-  // integer division is ~40 scalar instructions and a per-lane one 134 cycles (tools/ubench/prims.hip), which at one or two
-  // dozen tiles per product used to cost more than the MFMAs
-  int slot = slot0;
-  for (int bt = 0; bt < nbatch; ++bt)
-   for (int ti = 0; ti < tm; ++ti)
-    for (int tj = upper_only ? ti : 0; tj < tn; ++tj) {
-    const bool mine = slot == wave;
-    slot = slot + 1 == nw ? 0 : slot + 1;
-    if (!mine) continue;
+  // Tiles are dealt round-robin to the waves, starting at wave slot0.  A wave goes straight to ITS tiles (t = first, first + nw,
+  // ...) and decodes (batch, row tile, column tile) with scalar compare-and-subtract loops: walking all slots cost every wave
+  // -- the idle ones too -- a taken branch or two per slot (a 40-tile product: ~1.2 k cycles of bookkeeping per wave), and a
+  // scalar integer division is ~40 instructions.
+  const int per = upper_only ? (tm * (tm + 1)) >> 1 : tm * tn, ntiles = nbatch * per;
+  int first = wave - slot0;
+  if (first < 0) first += nw;
+  for (int t = first; t < ntiles; t += nw) {
+    int bt = 0, rem = t;
+    while (rem >= per) { rem -= per; ++bt; }
+    int ti = 0, tj;
+    if (upper_only) { int rowlen = tn; while (rem >= rowlen) { rem -= rowlen; ++ti; --rowlen; } tj = ti + rem; }
+    else { while (rem >= tn) { rem -= tn; ++ti; } tj = rem; }
     const int i0 = ti << 4, j0 = tj << 4;
     const int ia = min(i0 + r, M - 1), jb = min(j0 + r, N - 1);
     // the k index of the last step is clamped into range and its operand zeroed (ktail only)
     const int nfull = ktail ? nk - 1 : nk;
-    const TA *pa = A + bt * a_bs + ia * a_rs + q * a_ks;
-    const TB *pb = B + bt * b_bs + q * b_ks + jb * b_cs;
+    // (24-bit multiplies: LDS element offsets are far below 2^23, and v_mul_lo_u32 issues at quarter rate)
+    const TA *pa = A + (bt * a_bs + __mul24(ia, a_rs) + __mul24(q, a_ks));
+    const TB *pb = B + (bt * b_bs + __mul24(q, b_ks) + __mul24(jb, b_cs));
     dvec4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     int ks = 0;
     for (; ks + 4 <= nfull; ks += 4) {                  // four k-steps: all eight operands in flight before the first MFMA
@@ -131,7 +135,9 @@ __device__ inline int mm_lds(int nbatch, int M, int N, int K, const TA *A, int a
       if (i < M && j < N) store(bt, i, j, acc[reg]);
     }
   }
-  return slot;
+  int next = slot0 + ntiles;                            // where the next independent product continues the deal
+  while (next >= nw) next -= nw;
+  return next;
 }
 
 // float32 form of mm_lds (v_mfma_f32_16x16x4_f32: half the cycles of the float64 instruction, operands used as stored) for
@@ -149,16 +155,13 @@ __device__ inline void mm_lds_f32(int M, int N, int K, const float *A, int a_rs,
   const bool ktail = (K & 3) != 0;
   const int nfull = ktail ? nk - 1 : nk;
   const int sa = 4 * a_ks, sb = 4 * b_ks;
-  int slot = 0;
-  for (int ti = 0; ti < tm; ++ti)
-    for (int tj = 0; tj < tn; ++tj) {
-      const bool mine = slot == wave;
-      slot = slot + 1 == nw ? 0 : slot + 1;
-      if (!mine) continue;
+  for (int t = wave; t < tm * tn; t += nw) {             // straight to this wave's tiles (see mm_lds)
+      int ti = 0, tj = t;
+      while (tj >= tn) { tj -= tn; ++ti; }
       const int i0 = ti << 4, j0 = tj << 4;
       const int ia = min(i0 + r, M - 1), jb = min(j0 + r, N - 1);
-      const float *pa = A + ia * a_rs + q * a_ks;
-      const float *pb = B + q * b_ks + jb * b_cs;
+      const float *pa = A + (__mul24(ia, a_rs) + __mul24(q, a_ks));
+      const float *pb = B + (__mul24(q, b_ks) + __mul24(jb, b_cs));
       fvec4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       int ks = 0;
       for (; ks + 4 <= nfull; ks += 4) {
