@@ -1103,11 +1103,15 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   }
   lds_barrier();
   YSTAMP(6);
-  // short-side factor: q_j * sigma_j^(1/2)   (rows kk over waves, kept columns over lanes: no divisions)
+  // short-side factor: q_j * sigma_j^(1/2)   (rows kk over waves, kept columns over lanes: no divisions).  The same pass
+  // gathers the kept eigenvectors, scaled by sigma_j^(-1/2), into a dense [n][mk] matrix for the long-side product below
+  // (no per-element indirection through the order table there, no scaling in its epilogue)
   for (int kk = wave_u; kk < n; kk += NT >> 6)
    for (int sp = tid & 63; sp < mk; sp += 64) {
     const int j = k.sOrd[sp];
-    const float v = (float)(V[kk * ne + j] * k.dSq[sp]);
+    const double vq = V[kk * ne + j];
+    const float v = (float)(vq * k.dSq[sp]);
+    k.dVs[kk * mk + sp] = vq * k.dSq[ne + sp];
     if (short_rows) {                       // kk = row index i = h_*D + dk  -> behind core
       k.sCb[kk * mk + sp] = v;
       p.out_behind[(kk / D) * ob_s_h + (kk % D) * ob_s_d + sp * p.ob_s_m] = v;
@@ -1116,27 +1120,23 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       p.out_ahead[sp * p.oa_s_m + (q / g) * oa_s_d + (q % g) * oa_s_g + l] = v;
     }
    }
-  // long-side factor: (W q_j) / sigma_j^(1/2); columns s', inner index the short one
+  lds_barrier();
+  // long-side factor: W (q_j / sigma_j^(1/2)); columns s', inner index the short one
   if (short_rows) {
     // long index = ahead group x = (dk1, g_, l) = qq * L + l: the label is the batch, rows are qq = (dk1, g_)
-    small_gemm_f64(L, D * g, mk, n,
-                   [&](int l, int qq, int kk) { return (double)k.fB[kk * c + qq * L + l]; },
-                   [&](int l, int kk, int sp) { return V[kk * ne + k.sOrd[sp]]; },
-                   [&](int l, int qq, int sp, double acc) {
-                     const int dk1 = qq >= g ? 1 : 0;                     // D == 2
-                     const float v = (float)(acc * k.dSq[ne + sp]);
-                     p.out_ahead[sp * p.oa_s_m + dk1 * oa_s_d + (qq - dk1 * g) * oa_s_g + l] = v;
-                   });
+    mm_lds(L, D * g, mk, n, k.fB, 1, L, c, k.dVs, 0, mk, 1,
+           [&](int l, int qq, int sp, double acc) {
+             const int dk1 = qq >= g ? 1 : 0;                     // D == 2
+             p.out_ahead[__mul24(sp, p.oa_s_m) + dk1 * oa_s_d + __mul24(qq - dk1 * g, oa_s_g) + l] = (float)acc;
+           });
   } else {
     // long index = behind group x = (h_, dk) = h_ * D + dk: dk is the batch, rows are h_
-    small_gemm_f64(D, h, mk, n,
-                   [&](int dk, int h_, int kk) { return (double)k.fBp[(h_ * D + dk) * (c + 1) + kk]; },
-                   [&](int dk, int kk, int sp) { return V[kk * ne + k.sOrd[sp]]; },
-                   [&](int dk, int h_, int sp, double acc) {
-                     const float v = (float)(acc * k.dSq[ne + sp]);
-                     k.sCb[(h_ * D + dk) * mk + sp] = v;
-                     p.out_behind[h_ * ob_s_h + dk * ob_s_d + sp * p.ob_s_m] = v;
-                   });
+    mm_lds(D, h, mk, n, k.fBp, c + 1, D * (c + 1), 1, k.dVs, 0, mk, 1,
+           [&](int dk, int h_, int sp, double acc) {
+             const float v = (float)acc;
+             k.sCb[__mul24(h_ * D + dk, mk) + sp] = v;
+             p.out_behind[__mul24(h_, ob_s_h) + dk * ob_s_d + __mul24(sp, p.ob_s_m)] = v;
+           });
   }
   lds_barrier();
 
