@@ -675,7 +675,8 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // steps/s, cold start +8 %), 0.35 for smaller matrices whose sweeps are cheaper (C2, n = 20: 0.22 costs 17 %, 0.35 is
   // neutral in the steady state and +2 % cold)
   const double cthr = n >= 32 ? p.chol_thr : fmax(p.chol_thr, kCholThrSmall);
-  const bool use_chol = chol_possible && off2 > cthr * cthr * tr * tr;
+  // (block-uniform: every thread holds the same sums; told to the compiler so that the step below is scalar control flow)
+  const bool use_chol = __builtin_amdgcn_readfirstlane((int)(chol_possible && off2 > cthr * cthr * tr * tr)) != 0;
   XSTAMP(5);
   if (use_chol) {
     for (int e = tid; e < ne * ne; e += NT) Lm[e] = 0.0;
@@ -708,10 +709,10 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       inv0 = inv0 * fma(-0.5 * piv, inv0 * inv0, 1.5);
       if (tid == 0) { k.sFlag[4 + slot] = jp; k.dRed[61 + slot] = inv0; }
     };
-    if (tid < 64) pivot_search(0);
+    if (wave_u == 0) pivot_search(0);
     for (int kc = 0; kc < n; ++kc) {
       lds_barrier();                                     // A: pivot known; the previous update is complete
-      const int jp = k.sFlag[4 + (kc & 1)];
+      const int jp = __builtin_amdgcn_readfirstlane(k.sFlag[4 + (kc & 1)]);      // block-uniform: scalar loop exit, scalar row offset
       if (jp < 0) break;                                   // numerically rank deficient: the remaining columns stay zero
       const double inv = k.dRed[61 + (kc & 1)];
       double li[kCholPer];
@@ -723,13 +724,13 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
           const double2 c2 = *reinterpret_cast<const double2 *>(G0 + jp * ne + ej[u]);
           lj[u] = make_double2(c2.x * inv, c2.y * inv);
         }
-      if (tid < 64) {                                      // wave 0: column kc of L (original row index) and the diagonal
+      if (wave_u == 0) {                                   // wave 0: column kc of L (original row index) and the diagonal
         const double l = (tid < n && dgi >= 0.0) ? G0[jp * ne + tid] * inv : 0.0;
         if (tid < n) Lm[kc * ne + tid] = l;                // L stored transposed: row kc = column kc of L
         dgi = (tid == jp) ? -1.0 : (dgi >= 0.0 ? dgi - l * l : dgi);
       }
       lds_barrier();                                     // B: everybody holds its column values
-      if (tid < 64) {
+      if (wave_u == 0) {
         if (kc + 1 < n) pivot_search((kc + 1) & 1);
       } else {
 #pragma unroll
@@ -746,15 +747,10 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     lds_barrier();
     XSTAMP(6);
     // G' = L^T L into G0 (the trailing matrix is dead)
-    small_gemm_f64(1, n, n, n,
-                   [&](int, int a, int i) { return Lm[a * ne + i]; },
-                   [&](int, int i, int b) { return Lm[b * ne + i]; },
-                   [&](int, int a, int b, double v) { G0[a * ne + b] = v; });
+    mm_lds(1, n, n, n, Lm, 0, ne, 1, Lm, 0, 1, ne, [&](int, int a, int b, double v) { G0[a * ne + b] = v; });
     lds_barrier();
-    for (int e = tid; e < n * n; e += NT) {                // exact symmetry
-      const int i = e / n, j = e - i * n;
-      if (i > j) G0[i * ne + j] = G0[j * ne + i];
-    }
+    for (int i = wave_u; i < n; i += NT >> 6)              // exact symmetry (rows over waves, columns over lanes)
+      for (int j = tid & 63; j < i; j += 64) G0[i * ne + j] = G0[j * ne + i];
     lds_barrier();
   }
 
@@ -1033,13 +1029,12 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   lds_barrier();
   if (use_chol) {
     // back from the eigenvectors u of G' = L^T L to those of G: v = L u / sqrt(lambda) (columns stay at their positions)
-    small_gemm_f64(1, n, n, n,
-                   [&](int, int i, int kk) { return Lm[kk * ne + i]; },
-                   [&](int, int kk, int j) { return V[kk * ne + j]; },
-                   [&](int, int i, int j, double v) {
-                     const double ls = Gc[j * ne + j];
-                     Gn[i * ne + j] = ls > 1e-300 ? v / sqrt(ls) : 0.0;
-                   });
+    for (int j = tid; j < n; j += NT) {                  // 1 / sqrt(lambda_j) once per column (dSq is free until phase 9)
+      const double ls = Gc[j * ne + j];
+      k.dSq[j] = ls > 1e-300 ? 1.0 / sqrt(ls) : 0.0;
+    }
+    lds_barrier();
+    mm_lds(1, n, n, n, Lm, 0, 1, ne, V, 0, ne, 1, [&](int, int i, int j, double v) { Gn[i * ne + j] = v * k.dSq[j]; });
     V = Gn;
     lds_barrier();
   }
