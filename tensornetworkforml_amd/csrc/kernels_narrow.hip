@@ -696,7 +696,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     }
     double dgi = (tid < n) ? G0[tid * ne + tid] : -1.0;   // wave 0: remaining diagonal entry of row `tid`, -1 once chosen
     // pivot = largest remaining diagonal entry (a float key is enough to choose; lowest index on ties) and
-    // 1 / sqrt(pivot) by hardware float rsq + two Newton steps in float64.  Wave 0 searches the NEXT pivot while the
+    // 1 / sqrt(pivot) by hardware float rsq + one Newton step in float64.  Wave 0 searches the NEXT pivot while the
     // other waves update the trailing matrix: results alternate between two flag slots.
     auto pivot_search = [&](int slot) {
       const float key = (float)dgi;
@@ -705,42 +705,35 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       const int jp = (mx > 1e-26f && hit) ? __ffsll((long long)hit) - 1 : -1;
       const double piv = wave_read_f64(dgi, jp < 0 ? 0 : jp);
       double inv0 = (double)__builtin_amdgcn_rsqf((float)piv);
-      inv0 = inv0 * fma(-0.5 * piv, inv0 * inv0, 1.5);
-      inv0 = inv0 * fma(-0.5 * piv, inv0 * inv0, 1.5);
+      inv0 = inv0 * fma(-0.5 * piv, inv0 * inv0, 1.5);          // one Newton step: 1e-7 -> 1.5e-14 (this chain paces the factorisation)
       if (tid == 0) { k.sFlag[4 + slot] = jp; k.dRed[61 + slot] = inv0; }
     };
     if (wave_u == 0) pivot_search(0);
     for (int kc = 0; kc < n; ++kc) {
-      lds_barrier();                                     // A: pivot known; the previous update is complete
+      lds_barrier();                                     // pivot known; the previous update is complete
+      // The trailing matrix ping-pongs between the two G buffers (G1 is free until the Jacobi iteration): a step reads the
+      // pivot column and its own elements from one and writes the updated elements to the other, so nobody has to wait
+      // until everybody holds its column values -- ONE barrier per pivot instead of two.
+      const double *src = (kc & 1) ? G1 : G0;
+      double *dst = (kc & 1) ? G0 : G1;
       const int jp = __builtin_amdgcn_readfirstlane(k.sFlag[4 + (kc & 1)]);      // block-uniform: scalar loop exit, scalar row offset
       if (jp < 0) break;                                   // numerically rank deficient: the remaining columns stay zero
       const double inv = k.dRed[61 + (kc & 1)];
-      double li[kCholPer];
-      double2 lj[kCholPer];
-#pragma unroll
-      for (int u = 0; u < kCholPer; ++u)                   // column jp of the trailing matrix, before anybody updates it
-        if (ei[u] >= 0) {                                  // (row jp == column jp: symmetric, conflict-free)
-          li[u] = G0[jp * ne + ei[u]] * inv;
-          const double2 c2 = *reinterpret_cast<const double2 *>(G0 + jp * ne + ej[u]);
-          lj[u] = make_double2(c2.x * inv, c2.y * inv);
-        }
-      if (wave_u == 0) {                                   // wave 0: column kc of L (original row index) and the diagonal
-        const double l = (tid < n && dgi >= 0.0) ? G0[jp * ne + tid] * inv : 0.0;
+      if (wave_u == 0) {                                   // wave 0: column kc of L (original row index), the diagonal, next pivot
+        const double l = (tid < n && dgi >= 0.0) ? src[jp * ne + tid] * inv : 0.0;
         if (tid < n) Lm[kc * ne + tid] = l;                // L stored transposed: row kc = column kc of L
         dgi = (tid == jp) ? -1.0 : (dgi >= 0.0 ? dgi - l * l : dgi);
-      }
-      lds_barrier();                                     // B: everybody holds its column values
-      if (wave_u == 0) {
         if (kc + 1 < n) pivot_search((kc + 1) & 1);
       } else {
 #pragma unroll
         for (int u = 0; u < kCholPer; ++u)
-          if (ei[u] >= 0) {
-            double2 *g = reinterpret_cast<double2 *>(G0 + ei[u] * ne + ej[u]);
-            double2 v = *g;
-            v.x -= li[u] * lj[u].x;
-            v.y -= li[u] * lj[u].y;
-            *g = v;
+          if (ei[u] >= 0) {                                // (row jp == column jp: symmetric, conflict-free)
+            const double li = src[jp * ne + ei[u]] * inv;
+            const double2 c2 = *reinterpret_cast<const double2 *>(src + jp * ne + ej[u]);
+            double2 v = *reinterpret_cast<const double2 *>(src + ei[u] * ne + ej[u]);
+            v.x -= li * (c2.x * inv);
+            v.y -= li * (c2.y * inv);
+            *reinterpret_cast<double2 *>(dst + ei[u] * ne + ej[u]) = v;
           }
       }
     }
