@@ -8,5 +8,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_trace 
 cd $ROOT
 timeout -k 10 300 python3 tools/probe_timeline.py --rounds $OUT/tl_rounds.json > $OUT/tl_rounds.log 2>&1 || { tail -5 $OUT/tl_rounds.log; exit 1; }
 T=$(find $OUT/tl_trace -name '*_kernel_trace.csv' | head -1)
-python3 tools/probe_timeline.py --merge $T $OUT/tl_rounds.json | tee $OUT/tl_merge.txt
+python3 tools/probe_timeline.py --merge $T $OUT/tl_rounds.json | tee $OUT/tl_merge${TL_CLASSIC:+_classic}.txt
 find $OUT/tl_trace -name '*_kernel_trace.csv' -delete

@@ -22,6 +22,8 @@ def make_ctx():
     ctx.set_input(X, y)
     F2 = float(np.exp(ctx.forward_logabsmax() / N))
     ctx.scale_cores(1.0 / F2)
+    if os.environ.get('TL_CLASSIC'):          # the classic launch sequence: the update + SVD kernel runs with nothing beside it
+        ctx.set_step_pipeline(False)
     return ctx
 
 
@@ -53,7 +55,8 @@ elif sys.argv[1] == '--rounds':
     ctx.close()
 else:
     import csv
-    rows = [r for r in csv.DictReader(open(sys.argv[2])) if 'step_pipe_kernel' in r['Kernel_Name']]
+    kname = 'narrow_step_kernel' if os.environ.get('TL_CLASSIC') else 'step_pipe_kernel'
+    rows = [r for r in csv.DictReader(open(sys.argv[2])) if kname in r['Kernel_Name']]
     rd = json.load(open(sys.argv[3]))
     last = rows[-(N - 1):]                       # the N-1 step launches of the last pass (its prologue launch precedes them)
     dur = np.array([(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in last])
