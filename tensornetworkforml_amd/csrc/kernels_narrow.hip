@@ -1206,7 +1206,7 @@ void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st) {
 }
 
 // pipelined step (wide_pipe_device.h): ONE launch per sweep step.  Block 0 updates and splits the merged tensor of step k,
-// blocks 1..4 are its slice helpers (merged tensor and L2 term of step k), blocks w.wg0.. are the batch-side workgroups
+// blocks 1..w.wg0-1 are its slice helpers (merged tensor and L2 term of step k: D*D slices, cut into row parts), blocks w.wg0.. are the batch-side workgroups
 // that turn B_new(k) into f and the pre-gradient of step k+1 while block 0 runs the SVD.  With w.wg0 == 0 the launch
 // carries batch-side workgroups only (start of a sweep, or after a classic step).
 __global__ __launch_bounds__(kNarrowThreads) void step_pipe_kernel(NarrowParams p, WidePipeParams w) {
