@@ -75,20 +75,43 @@ __global__ __launch_bounds__(kChainThreads) void env_chain_kernel(
 
   float *cur = sE0, *nxt = sE1;
   if (tid < kChainTS) { cur[tid] = 1.0f; sScale[tid] = 0.f; sMax[tid] = 0u; }
+  // Software pipeline over the sites: the descriptor of site i + 2 and the core elements + features of site i + 1 are
+  // requested while site i is computed (a site used to cost two dependent memory round trips -- descriptor, then core --
+  // and three integer divisions per staged element: 2.5 us of a 784-site chain's 1.9 ms per site).
+  constexpr int kPre = 4;                         // core elements per thread held in registers (bond <= 32); the rest is staged directly
+  ChainSite cs = sites[0], cs1 = sites[n_sites > 1 ? 1 : 0];
+  float pre[kPre], prex = 0.f;
+  auto core_at = [&](const ChainSite &c, int e, float inv_o) -> float {
+    const float *src = (c.is_label ? labcore : cores) + c.core_off;
+    const int r = (int)(((float)e + 0.5f) * inv_o), o = e - r * c.n_out;      // exact quotient of small integers
+    return src[(r / kD) * c.s_in + (r % kD) * c.s_d + o * c.s_out];
+  };
+  auto issue = [&](const ChainSite &c) {
+    const int na = c.n_in * kD * c.n_out;
+    const float inv_o = 1.0f / (float)c.n_out;
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      const int e = tid + u * kChainThreads;
+      pre[u] = e < na ? core_at(c, e, inv_o) : 0.f;
+    }
+    if (tid < kChainTS * kD) prex = X[((size_t)c.x_site * b_pad + blockIdx.x * kChainTS + tid / kD) * kD + (tid % kD)];
+  };
+  issue(cs);
   for (int i = 0; i < n_sites; ++i) {
-    const ChainSite cs = sites[i];
-    const float *src = (cs.is_label ? labcore : cores) + cs.core_off;
     const int na = cs.n_in * kD * cs.n_out;
-    for (int e = tid; e < na; e += kChainThreads) {
-      const int o = e % cs.n_out, r = e / cs.n_out;
-      const int d = r % kD, in = r / kD;
-      sA[e] = src[in * cs.s_in + d * cs.s_d + o * cs.s_out];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      const int e = tid + u * kChainThreads;
+      if (e < na) sA[e] = pre[u];
     }
-    if (tid < kChainTS * kD) {
-      const int ss = blockIdx.x * kChainTS + tid / kD;
-      sX[tid] = X[((size_t)cs.x_site * b_pad + ss) * kD + (tid % kD)];
+    if (na > kPre * kChainThreads) {
+      const float inv_o = 1.0f / (float)cs.n_out;
+      for (int e = tid + kPre * kChainThreads; e < na; e += kChainThreads) sA[e] = core_at(cs, e, inv_o);
     }
-    __syncthreads();
+    if (tid < kChainTS * kD) sX[tid] = prex;
+    const ChainSite cs2 = sites[i + 2 < n_sites ? i + 2 : n_sites - 1];
+    lds_barrier();                                // LDS only: nobody waits for the environment stores of the previous site
+    if (i + 1 < n_sites) issue(cs1);              // in flight while this site is computed
     const float x0 = sX[sl * kD], x1 = sX[sl * kD + 1];
     for (int o = og; o < cs.n_out; o += OG) {
       float a0 = 0.f, a1 = 0.f;
@@ -107,7 +130,7 @@ __global__ __launch_bounds__(kChainThreads) void env_chain_kernel(
         f[(size_t)o * b_pad + s] = v;
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (LOGMODE) {
       const float mx = __uint_as_float(sMax[sl]);
       const float inv = (mx > 0.f && isfinite(mx)) ? 1.0f / mx : 1.0f;
@@ -121,6 +144,7 @@ __global__ __launch_bounds__(kChainThreads) void env_chain_kernel(
       __syncthreads();
     }
     float *t = cur; cur = nxt; nxt = t;
+    cs = cs1; cs1 = cs2;
   }
   if (LOGMODE) {
     // after the label site the renormalised max |f| of every sample is 1: log max|f| = sScale
