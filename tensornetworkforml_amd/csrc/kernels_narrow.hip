@@ -550,16 +550,18 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   //   W(x, kk) = short_rows ? Bm[kk][x] : Bm[x][kk]   with Bm = B_new as (r x c) row-major
   double *G0 = k.Z, *G1 = k.Z + ne * ne, *V0 = k.Z + 2 * ne * ne;
   // float64 matrix and vector pipes of gfx950 both retire 16 FMA per cycle per SIMD, so the MFMA count per SIMD is
-  // what matters: the upper 16x16 tiles (G is symmetric) are cut into kGramSplit slices along the long index and
-  // the (tile, slice) items dealt round-robin to all 16 waves; slice partials land in the four ne x ne buffers of
-  // the Jacobi region and are summed in slice order (deterministic).
-  constexpr int kGramSplit = 4;
+  // what matters: the upper 16x16 tiles (G is symmetric) are cut into slices along the long index -- as many (4, 2 or 1) as
+  // still give every wave at most ONE (tile, slice) item (n = 40: 6 tiles x 2 slices; n = 20: 3 x 4), else 4 -- and the
+  // items dealt round-robin to the 16 waves; slice partials land in the four ne x ne buffers of the Jacobi region and are
+  // summed in slice order (deterministic).
   double g_tr = 0.0, g_dg2 = 0.0, g_off2 = 0.0;
   {
     double *P0 = G0, *P1 = G1, *P2 = V0, *P3 = k.Z + 3 * ne * ne;
     const int lane = tid & 63, wave = wave_u, rr = lane & 15, qq = lane >> 4;
-    const int tm = (n + 15) >> 4;
-    const int kchunk = ((len + kGramSplit - 1) / kGramSplit + 3) & ~3;       // multiple of the MFMA k = 4
+    const int tm = (n + 15) >> 4, ntile_g = (tm * (tm + 1)) >> 1;
+    const int gshift = ntile_g * 4 <= (NT >> 6) ? 2 : (ntile_g * 2 <= (NT >> 6) ? 1 : (ntile_g <= (NT >> 6) ? 0 : 2));
+    const int gsplit = 1 << gshift;
+    const int kchunk = ((len + gsplit - 1) / gsplit + 3) & ~3;       // multiple of the MFMA k = 4
     // (tile, slice) items dealt round-robin to the waves: nested counters, no integer division (a per-lane division costs
     // 134 cycles, a wave-uniform one ~40 scalar instructions: tools/ubench/prims.hip)
 #ifdef TNML_EXP_GRAM_TWICE      // instruction-cache experiment: the same code a second time (probe points 2/3 = second pass)
@@ -572,10 +574,10 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     const int wave_s = wave;
     const float *Wb = short_rows ? k.fBp : k.fB;
     const int rs = short_rows ? c + 1 : 1, cs = short_rows ? 1 : c;
-    const int nitems = ((tm * (tm + 1)) >> 1) * kGramSplit;
+    const int nitems = ntile_g * gsplit;
     for (int item = wave_s; item < nitems; item += NT >> 6) {
-      const int ks = item & (kGramSplit - 1);
-      int t = item >> 2, ti = 0, rowlen = tm;              // kGramSplit == 4
+      const int ks = item & (gsplit - 1);
+      int t = item >> gshift, ti = 0, rowlen = tm;
       while (t >= rowlen) { t -= rowlen; ++ti; --rowlen; }
       const int tj = ti + t;
       const int i0 = ti << 4, j0 = tj << 4;
@@ -630,7 +632,9 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       for (int j = tid & 63; j < ne; j += 64)
         if (i <= j) {
           const int e = i * ne + j;
-          const double v = ((P0[e] + P1[e]) + P2[e]) + P3[e];
+          double v = P0[e];
+          if (gsplit > 1) v += P1[e];
+          if (gsplit > 2) v = (v + P2[e]) + P3[e];
           P0[e] = v;                                              // P0 == G0: in place
           if (i < j) { G0[j * ne + i] = v; g_off2 += 2.0 * v * v; }
           else { g_tr += v; g_dg2 += v * v; }
