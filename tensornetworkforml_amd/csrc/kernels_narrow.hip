@@ -1113,14 +1113,20 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     }
    }
   lds_barrier();
-  // long-side factor: W (q_j / sigma_j^(1/2)); columns s', inner index the short one
+  // long-side factor: W (q_j / sigma_j^(1/2)); columns s', inner index the short one.  When the short side is the behind core
+  // (short_rows), the first product of the next behind norm environment, T2 = Nh . Cb, needs nothing the long-side product
+  // writes: the two run back to back without a barrier, their tiles dealt to the waves as one list.
+  const int DM = D * mk;
+  auto store_T2 = [&](int, int i, int j, double v) { k.dT2[i * DM + j] = v; };
   if (short_rows) {
     // long index = ahead group x = (dk1, g_, l) = qq * L + l: the label is the batch, rows are qq = (dk1, g_)
-    mm_lds(L, D * g, mk, n, k.fB, 1, L, c, k.dVs, 0, mk, 1,
+    const int slot = mm_lds(L, D * g, mk, n, k.fB, 1, L, c, k.dVs, 0, mk, 1,
            [&](int l, int qq, int sp, double acc) {
              const int dk1 = qq >= g ? 1 : 0;                     // D == 2
              p.out_ahead[__mul24(sp, p.oa_s_m) + dk1 * oa_s_d + __mul24(qq - dk1 * g, oa_s_g) + l] = (float)acc;
            });
+    // T2[h_, (d, s'')] = sum_h' Nh[h_, h'] Cb[h', (d, s'')]
+    if (p.Nh_new) mm_lds(1, h, DM, h, k.dNh, 0, h, 1, k.sCb, 0, DM, 1, store_T2, false, slot);
   } else {
     // long index = behind group x = (h_, dk) = h_ * D + dk: dk is the batch, rows are h_
     mm_lds(D, h, mk, n, k.fBp, c + 1, D * (c + 1), 1, k.dVs, 0, mk, 1,
@@ -1136,11 +1142,11 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // ---- phase 10: behind norm environment of the next step ------------------------------------------
   YSTAMP(10);
   if (p.Nh_new) {
-    // T2[h_, (d, s'')] = sum_h' Nh[h_, h'] Cb[h', (d, s'')]
-    const int DM = D * mk;
-    mm_lds(1, h, DM, h, k.dNh, 0, h, 1, k.sCb, 0, DM, 1, [&](int, int i, int j, double v) { k.dT2[i * DM + j] = v; });
-    YSTAMP(11);
-    lds_barrier();
+    if (!short_rows) {
+      mm_lds(1, h, DM, h, k.dNh, 0, h, 1, k.sCb, 0, DM, 1, store_T2);
+      YSTAMP(11);
+      lds_barrier();
+    }
     // Nh_new[s', s''] = sum_{(h_, d)} Cb[(h_, d), s'] T2[(h_, d), s'']
     mm_lds(1, mk, mk, h * D, k.sCb, 0, 1, mk, k.dT2, 0, mk, 1,
            [&](int, int i, int j, double v) { p.Nh_new[i * mk + j] = v; });
