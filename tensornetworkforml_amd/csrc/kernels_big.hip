@@ -574,7 +574,10 @@ static bool big_launch(const char *name, bool check, K kernel, dim3 grid, dim3 b
   return true;
 }
 
-bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check) {
+// The part of the chain that needs neither the batch-summed gradient nor anything else the batch kernel of this step
+// produces: the merged tensor and T = Nh^T . B.  The host may enqueue it on a second stream beside the batch kernel
+// (`prep_only`), and then asks the chain proper to skip it (`skip_prep`).
+bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check, bool prep_only, bool skip_prep) {
   const int D = kD, Bs = p.bsize;
   const int r = D * p.h, c = D * p.g * p.L;
   const bool short_rows = r <= c;
@@ -590,11 +593,12 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
 #define BIG(kern, grid, block, lds, ...) \
   if (!big_launch(#kern, check, kern, grid, block, lds, st, __VA_ARGS__)) return false
   if (!Bf) {
-    BIG(big_merge_kernel, dim3(nbe), dim3(kBT), 0, p, s.Bf);
+    if (!skip_prep) BIG(big_merge_kernel, dim3(nbe), dim3(kBT), 0, p, s.Bf);
     Bf = s.Bf;
   }
   double *ws = p.dbg;                          // the capture block doubles as the workspace of this path
-  if (p.l2_flag) BIG(big_l2_T_kernel, dim3(nbe), dim3(kBT), 0, p, Bf, s.T);
+  if (p.l2_flag && !skip_prep) BIG(big_l2_T_kernel, dim3(nbe), dim3(kBT), 0, p, Bf, s.T);
+  if (prep_only) return true;
   BIG(big_wd_kernel, dim3(nb), dim3(kBT), 0, p, Bf, (const double *)s.T, ws, s.part);
   BIG(big_update_kernel, dim3(nb), dim3(kBT), 0, p, ws, (const double *)s.part, nb);
   if (p.stop_after_update) return true;

@@ -48,6 +48,8 @@ struct tnml_ctx {
   int b = 0, b_pad = 0, b_cap = 0;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;             // large-tensor steps: merged tensor and Nh^T.B beside the batch kernel
+  hipEvent_t ev_main = nullptr, ev_prep = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
   // host bookkeeping
   std::vector<int> bond;
@@ -201,6 +203,9 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   c->N = N; c->D = D; c->L = L; c->Mmax = Mmax; c->device = device;
   c->bond.assign(N - 1, 1);
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipEventCreate(&c->pev0)); HIP_TRY(hipEventCreate(&c->pev1));
   c->core_stride = (size_t)Mmax * D * Mmax;
@@ -258,6 +263,9 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->pev0) (void)hipEventDestroy(c->pev0);
   if (c->pev1) (void)hipEventDestroy(c->pev1);
+  if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+  if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return TNML_OK;
@@ -718,7 +726,7 @@ static int narrow_path(const tnml_ctx *c, int h, int g, int s, int L, int m) {
   return 1;
 }
 
-static int run_narrow(tnml_ctx *c, NarrowParams &n, int path) {
+static int run_narrow(tnml_ctx *c, NarrowParams &n, int path, bool skip_prep = false) {
   if (path == 0) {
     size_t lds = narrow_lds_bytes(n.h, n.g, n.s, n.L, n.m);
     if (n.fused && !n.prep_ready) lds = std::max(lds, prep_slice_lds_bytes(n.h, n.g, n.s, n.L));   // slice workgroups ride along
@@ -729,7 +737,7 @@ static int run_narrow(tnml_ctx *c, NarrowParams &n, int path) {
   int rc = ensure_big(c);
   if (rc) return rc;
   n.dbg = c->dbg;                       // the capture block is this path's workspace
-  if (!launch_narrow_big(n, c->big, c->stream, c->check_launches)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
+  if (!launch_narrow_big(n, c->big, c->stream, c->check_launches, false, skip_prep)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
   return TNML_OK;
 }
 
@@ -1068,6 +1076,18 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       PrepParams prep{};
       prep.lab = n.lab; prep.pl = n.pl; prep.Nh = n.Nh; prep.Ng = n.Ng; prep.h = h; prep.g = g; prep.s = s; prep.L = L;
       prep.l2_flag = n.l2_flag; prep.prepB = c->prepB; prep.prepG = c->prepG;
+      // Large-tensor step: the merged tensor and T = Nh^T . B need nothing this step's batch kernel produces -- they run on
+      // a second stream beside it (two of the chain's fourteen launches, 30 us of a 380 us C5 step), joined by an event
+      // before the weight-decay kernel reads them.
+      bool prep_ahead = false;
+      if (npath == 1 && mode == 0 && !Bdirect_dev) {
+        { int rc = ensure_big(c); if (rc) return rc; }
+        HIP_TRY(hipEventRecord(c->ev_main, c->stream));                  // everything the previous step wrote
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_main, 0));
+        if (!launch_narrow_big(n, c->big, c->stream2, c->check_launches, true, false)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
+        HIP_TRY(hipEventRecord(c->ev_prep, c->stream2));
+        prep_ahead = true;
+      }
       prof_begin(c);
       bool prep_done = false;
       if (!launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream, &prep_done))
@@ -1088,7 +1108,8 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       }
       if (c->comm) NCCL_TRY(ncclAllReduce(c->red, c->red, bsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
       prof_begin(c);
-      { int rc = run_narrow(c, n, npath); if (rc) return rc; }
+      if (prep_ahead) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_prep, 0));
+      { int rc = run_narrow(c, n, npath, prep_ahead); if (rc) return rc; }
       prof_end(c, 3);
       c->sweep_launches += (fused_now ? 2 : 3) + (npath == 1 ? 11 : 0);
       c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;

@@ -161,7 +161,8 @@ constexpr int kBigMaxN = 128;
 constexpr int kBigParts = 512;
 size_t big_jacobi_lds_bytes(int n);
 // false: a launch of the path was illegal or (check) failed; big_launch_error() names it
-bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check);
+bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check, bool prep_only = false,
+                       bool skip_prep = false);
 const char *big_launch_error();
 size_t narrow_lds_bytes(int h, int g, int s, int L, int m);
 void launch_norm_chain(const NormChainSite *sites_dev, int n_sites, const float *cores, double *env_base,
