@@ -137,8 +137,8 @@ def cpu_baseline_reference_form(N, M, D, L, st, f, y1h, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=6)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)      # the driver's command: --steps 20 --warmup 5
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--policy', default='fixed', choices=['fixed', 'reference'])
     ap.add_argument('--no-l2', action='store_true', help='weight decay as wd*B instead of the L2 norm term')
