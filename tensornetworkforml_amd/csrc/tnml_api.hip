@@ -984,6 +984,10 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       wp.do_ext = k >= 1; wp.do_f = 1; wp.wait_flag = 1;
       wp.do_z = (k + 1 <= N - 2);
       if (wp.do_z && !wide_pipe_fits(c, wp)) wp.do_z = 0;            // the next step will start from its own prologue
+      if (wp.do_z && wp.nwide <= 256 && (size_t)16 * (wp.zsize + kMetricSlots) * sizeof(float) <= wide_pipe_lds_bytes(wp) - 16) {
+        // a small pre-gradient (bonds of a few): one reduction level, the sixteen chunk sums through the last arriver's LDS
+        wp.gsz = wp.nwide; wp.ngroups = 1; wp.one_level = 1;
+      }
       if (wp.do_z && c->pipe_tiles > wp.tiles_per_wg && nn >= 32) {
         // the SVD of this step is long (short side >= 32): a batch-side workgroup accumulates several sample tiles in
         // registers before it writes its partial pre-gradient -- proportionally fewer partial tensors to write and re-read

@@ -70,6 +70,7 @@ struct WidePipeParams {
   unsigned *gcnt;        // [ngroups] arrival counters, zero between launches
   unsigned *tcnt;        // top-level arrival counter
   int nwide, gsz, ngroups;
+  int one_level;         // small pre-gradient: the last arriver of the single group sums all partials through its LDS (host checked the room)
   int wg0;               // blockIdx of the first batch-side workgroup
   int tiles_per_wg;      // sample tiles (kTS samples) a workgroup accumulates before it writes its partial tensor
   int ntiles;            // b_pad / kTS
@@ -421,6 +422,37 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
       else *reinterpret_cast<float4 *>(dst + 4 * e) = a;
     }
   };
+  if (p.one_level) {
+    // Small pre-gradients (bonds of a few: the chain ends, and every step under the reference's truncation rule, where the
+    // batch side IS the step): ONE level.  The last arriver sums all partials -- thread (chunk c, element e) adds the c-th
+    // sixteenth of them in slab order, the sixteen chunk sums meet in LDS and are added in chunk order (fixed order:
+    // deterministic) -- and writes the reduced tensor itself: no group sums, no second ticket, no second acquire.
+    acquire_all();
+    const int n4 = (n + 3) / 4, per = (g_n + 15) / 16;
+    const float inv_n4 = 1.0f / (float)n4;
+    float4 *part = reinterpret_cast<float4 *>(smem);
+    for (int idx = tid; idx < 16 * n4; idx += NT) {
+      const int c = (int)(((float)idx + 0.5f) * inv_n4), e = idx - c * n4;       // exact quotient of small integers
+      const int k_lo = c * per, cnt = min(g_n, k_lo + per) - k_lo;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        v[k] = k < cnt ? *reinterpret_cast<const float4 *>(p.slabs + (size_t)(k_lo + k) * p.slab_stride + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
+      part[idx] = a;
+    }
+    lds_barrier();
+    for (int e = tid; e < n4; e += NT) {
+      float4 a = part[e];
+#pragma unroll
+      for (int c = 1; c < 16; ++c) { const float4 b = part[c * n4 + e]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+      *reinterpret_cast<float4 *>(p.zred + 4 * e) = a;
+    }
+    if (tid == 0) __hip_atomic_store(p.gcnt + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    return;
+  }
   // level 1: the group's slabs in slab order
   acquire_all();
   sum_slabs(p.slabs + (size_t)g_lo * p.slab_stride, g_n, p.gslabs + (size_t)grp * p.slab_stride, true);
