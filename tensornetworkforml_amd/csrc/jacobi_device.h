@@ -102,6 +102,11 @@ template <int CTRL> __device__ inline double dpp_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
+template <int CTRL> __device__ inline float dpp_f32(float v) {
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, CTRL, 0xf, 0xf, false));
+}
+
 // wave-wide maximum of a float without touching the LDS crossbar: xor-butterfly inside every 16-lane row by DPP
 // (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row maxima by v_readlane
 __device__ inline float wave_max_f32(float v) {

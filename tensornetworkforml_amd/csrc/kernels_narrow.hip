@@ -123,9 +123,6 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
   const int h = p.h, g = p.g, s = p.s, L = p.L, Bs = p.bsize;
   const int blk = blockIdx.x - 1;
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-#ifdef TNML_EXP_FINE_STAMPS
-  const unsigned long long c_start = __builtin_amdgcn_s_memtime();
-#endif
   if (blk < p.nred) {
     float *part = (float *)smem_raw;                       // [16][64]
     const int el = tid & 63, chunk = tid >> 6;
@@ -154,17 +151,7 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
     q.lab = p.lab; q.pl = p.pl; q.Nh = p.Nh; q.Ng = p.Ng; q.h = h; q.g = g; q.s = s; q.L = L; q.l2_flag = p.l2_flag;
     q.prepB = p.prepB; q.prepG = p.prepG;
     q.nparts = p.pipe ? (p.wait_count - p.nred) / (kD * kD) : 1;
-#ifdef TNML_EXP_HELPER_TWICE     // instruction-fetch experiment: the (idempotent) helper body twice through the same code
-#pragma nounroll
-    for (int rep = 0; rep < 2; ++rep) {
-      prep_slice_block(q, blk - p.nred, smem_raw, true, (p.stamps && blk - p.nred == 0) ? p.stamps + 88 + (rep ? 12 : 0) : nullptr);
-      __syncthreads();
-    }
-#elif defined(TNML_EXP_FINE_STAMPS)
-    prep_slice_block(q, blk - p.nred, smem_raw, true, (p.stamps && blk - p.nred == 0) ? p.stamps + 88 : nullptr);
-#else
     prep_slice_block(q, blk - p.nred, smem_raw, true);
-#endif
   }
   // hand-off to workgroup 0 (other CU, possibly other XCD: L1 and L2 are not coherent across them), first row of the
   // hand-off table of MI355X_MICROARCH.md: every handed-off byte was stored with an agent-scope (sc1, write-through)
@@ -172,11 +159,6 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
   // write-back to wait for); workgroup 0 polls it relaxed and reads the data with agent-scope (sc1) loads
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-#ifdef TNML_EXP_FINE_STAMPS
-  if (p.stamps && tid == 0 && blk - p.nred == 0) p.stamps[88 + 7] = (double)(__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1));
-  if (p.stamps && tid == 0 && blk - p.nred == 0) p.stamps[88 + 8] = (double)(t_start & ((1ull << 40) - 1));
-  if (p.stamps && tid == 0 && blk - p.nred == 0) p.stamps[88 + 10] = (double)(__builtin_amdgcn_s_memtime() - c_start);
-#endif
   if (tid == 0) {
     if (p.stamps && p.counters) {      // diagnostic: first start and last finish of either helper role, 100 MHz ticks
       atomicMin(p.counters + (blk < p.nred ? 4 : 5), t_start);
@@ -211,26 +193,8 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 
   unsigned long long t_c0 = 0, t_r0 = 0, t_c1 = 0, t_c2 = 0, t_c2b = 0, t_c2c = 0;
   unsigned long long t_p[5] = {0, 0, 0, 0, 0};
-#ifdef TNML_EXP_FINE_STAMPS
-  unsigned long long t_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t_y[24];
-  for (int i = 0; i < 24; ++i) t_y[i] = 0;
-#define XSTAMP(i) if (p.stamps && tid == 0) t_x[i] = __builtin_amdgcn_s_memtime()
-#define YSTAMP(i) if (p.stamps && tid == 0) t_y[i] = __builtin_amdgcn_s_memtime()
-  // per-wave probe points (lane 0 of every wave; absolute shader cycles, the host subtracts wave 0's point 0)
-  unsigned long long t_w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define WPROBE(i) if (p.stamps && (tid & 63) == 0) t_w[i] = __builtin_amdgcn_s_memtime()
-#else
-#define XSTAMP(i)
-#define YSTAMP(i)
-#define WPROBE(i)
-#endif
 #define TNML_STAMP(i) if (p.stamps && tid == 0) t_p[i] = __builtin_amdgcn_s_memtime()
   if (p.stamps && tid == 0) { t_c0 = __builtin_amdgcn_s_memtime(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
-#ifdef TNML_EXP_FINE_STAMPS
-  if (p.stamps && tid == 0) p.stamps[88 + 9] = (double)(t_r0 & ((1ull << 40) - 1));
-#endif
-  WPROBE(0);
   // ---- pipelined step: raw gradient dB[h_, rest] = sum_i' A_{k-1}[i', h_] Z_k[i', rest] (wide_pipe_device.h); both operands
   // were completed by the previous launch, so this runs before anything of this launch is waited for
   const int RWz = kD * kD * p.g * p.L;
@@ -265,7 +229,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       rnh[u] = (p.Nh && e < h * h) ? p.Nh[e] : 1.0;
       rng[u] = (p.Ng && e < g * g) ? p.Ng[e] : 1.0;
     }
-    YSTAMP(0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int e = 4 * (tid + u * NT); if (e < nz) *reinterpret_cast<float4 *>(sZ + e) = rz[u]; }
 #pragma unroll
@@ -280,19 +243,9 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       if (e < h * h) k.dNh[e] = rnh[u];
       if (e < g * g) k.dNg[e] = rng[u];
     }
-    YSTAMP(1);
-    WPROBE(1);
     lds_barrier();
-    YSTAMP(2);
     if (!p.z_first)
       mm_lds_f32(h, RWz, zr, sZc, 1, h, sZ, RWz, 1, [&](int i, int j, float v) { k.dT[i * RWz + j] = (double)v; });
-    YSTAMP(3);
-#ifdef TNML_EXP_FINE_STAMPS
-    const unsigned long long t_rc = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifndef TNML_EXP_GRAM_TWICE
-    WPROBE(2);
-#endif
     if (!p.prep_ready) {
       // merged tensor and L2 term from the slice workgroups of THIS launch: wait for their arrivals, then agent-scope loads,
       // all in flight together
@@ -307,16 +260,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
         }
         if (spins >= (1 << 22)) atomicOr(p.status, 4);
         __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef TNML_EXP_FINE_STAMPS
-        if (p.stamps && p.counters) {      // ticks of the 100 MHz counter relative to this workgroup's start
-          p.stamps[28] = (double)(__builtin_amdgcn_s_memrealtime() - t_r0);      // wait over
-          p.stamps[29] = (double)(t_rc - t_r0);                                  // contraction done (poll starts)
-          p.stamps[31] = (double)(long long)(p.counters[5] - t_r0);              // first slice helper started
-          p.stamps[32] = (double)(long long)(p.counters[7] - t_r0);              // last slice helper done
-          p.stamps[33] = (double)spins;
-          p.counters[5] = ~0ull; p.counters[7] = 0ull;
-        }
-#endif
       }
       lds_barrier();
       // 16-byte agent-scope loads, all in flight together (Bs is a multiple of D * D = 4)
@@ -331,13 +274,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const int e = 2 * (tid + u * NT); if (p.l2_flag && e < Bs) *reinterpret_cast<tn_uvec4 *>(k.dG + e) = qg[u]; }
     }
-    YSTAMP(4);
-#ifdef TNML_EXP_FINE_STAMPS
-    if (p.stamps && tid == 0) p.stamps[30] = (double)(__builtin_amdgcn_s_memrealtime() - t_r0);     // payload in LDS
-#endif
-#ifndef TNML_EXP_GRAM_TWICE
-    WPROBE(3);
-#endif
   } else if (p.pipe && !p.z_first) {
     const float *zc = p.zcore.base;
     const int zs_in = p.zcore.s_in, zs_d = p.zcore.s_d, zs_out = p.zcore.s_out;
@@ -471,13 +407,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     sumB += fabs(bv);
     sumD += fabs(dv);
   }
-  XSTAMP(0);
-#ifndef TNML_EXP_GRAM_TWICE
-  WPROBE(4);
-#endif
   block_sum3<0>(sumB, sumD, l2, k.dRed);
-  XSTAMP(1);
-  WPROBE(5);
 
   // ---- phase 5: clip + update (Network_class.py:755-761) ----------------------------------------
   double factor = (double)p.lr;
@@ -528,8 +458,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       sc[2] = sumD;
     }
   }
-  XSTAMP(2);
-  WPROBE(6);
   lds_barrier();   // dT/dG are dead from here on; Z aliases them
   // B_new is complete in memory: the batch-side workgroups of this launch may form f and the next pre-gradient from it
   // while this workgroup goes on to the SVD
@@ -545,7 +473,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   }
 
   TNML_STAMP(3);
-  WPROBE(7);
   // ---- phase 6: Gram matrix in float64 (padded to ne x ne with a zero row/column), V = I ----------
   //   W(x, kk) = short_rows ? Bm[kk][x] : Bm[x][kk]   with Bm = B_new as (r x c) row-major
   double *G0 = k.Z, *G1 = k.Z + ne * ne, *V0 = k.Z + 2 * ne * ne;
@@ -555,7 +482,8 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // items dealt round-robin to the 16 waves; slice partials land in the four ne x ne buffers of the Jacobi region and are
   // summed in slice order (deterministic).
   double g_tr = 0.0, g_dg2 = 0.0, g_off2 = 0.0;
-  {
+  auto gram_phase = [&]() {
+    double a_tr = 0.0, a_dg2 = 0.0, a_off2 = 0.0;            // locals: the captured sums would live in memory
     double *P0 = G0, *P1 = G1, *P2 = V0, *P3 = k.Z + 3 * ne * ne;
     const int lane = tid & 63, wave = wave_u, rr = lane & 15, qq = lane >> 4;
     const int tm = (n + 15) >> 4, ntile_g = (tm * (tm + 1)) >> 1;
@@ -564,11 +492,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     const int kchunk = ((len + gsplit - 1) / gsplit + 3) & ~3;       // multiple of the MFMA k = 4
     // (tile, slice) items dealt round-robin to the waves: nested counters, no integer division (a per-lane division costs
     // 134 cycles, a wave-uniform one ~40 scalar instructions: tools/ubench/prims.hip)
-#ifdef TNML_EXP_GRAM_TWICE      // instruction-cache experiment: the same code a second time (probe points 2/3 = second pass)
-#pragma nounroll
-    for (int gram_rep = 0; gram_rep < 2; ++gram_rep) {
-    if (gram_rep == 1) { WPROBE(2); }
-#endif
     // this wave's (tile, slice) items, decoded from a wave-uniform index with scalar instructions only (the wave index is
     // made uniform for the compiler by v_readfirstlane); W(x, kk) = Wb[x * rs + kk * cs]
     const int wave_s = wave;
@@ -612,19 +535,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
         if (i < ne && j < ne) Pk[i * ne + j] = (i < n && j < n) ? acc[reg] : 0.0;     // padding row / column = 0
       }
     }
-#ifdef TNML_EXP_GRAM_TWICE
-    if (gram_rep == 0) { WPROBE(8); lds_barrier(); WPROBE(9); } else { WPROBE(3); }
-    }
-#else
-    WPROBE(8);
-#endif
     lds_barrier();
-    XSTAMP(3);
-#ifdef TNML_EXP_GRAM_TWICE
-    WPROBE(4);
-#else
-    WPROBE(9);
-#endif
     // sum of the slices, in slice order, written to both triangles (exact symmetry; tiles below the diagonal were never
     // written, and inside a diagonal tile only i <= j is read).  Rows over waves, columns over lanes: no division.  The
     // same pass collects trace, sum of squared diagonal and of squared off-diagonal entries.
@@ -636,12 +547,12 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
           if (gsplit > 1) v += P1[e];
           if (gsplit > 2) v = (v + P2[e]) + P3[e];
           P0[e] = v;                                              // P0 == G0: in place
-          if (i < j) { G0[j * ne + i] = v; g_off2 += 2.0 * v * v; }
-          else { g_tr += v; g_dg2 += v * v; }
+          if (i < j) { G0[j * ne + i] = v; a_off2 += 2.0 * v * v; }
+          else { a_tr += v; a_dg2 += v * v; }
         }
-  }
-  XSTAMP(4);
-  WPROBE(10);
+    g_tr = a_tr; g_dg2 = a_dg2; g_off2 = a_off2;
+  };
+  gram_phase();
   // Tournament in POSITION space: the pairs of a round are always the positions (2k, 2k+1); after
   // the rotations every row/column moves to position pi(pos) of the next round (circle method:
   // position 0 fixed, top row shifts right, bottom row shifts left).  The move is free: the updated
@@ -656,16 +567,334 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     k.sPiInv[nxt] = pos;
   }
   TNML_STAMP(4);
-  WPROBE(11);
   // scale G to trace ~ 1 by an exact power of two (undone on the eigenvalues in phase 8); the statistics of the summation
   // pass decide about the Cholesky step (a ratio: the scale drops out)
-  block_sum3<1>(g_tr, g_dg2, g_off2, k.dRed);              // its barrier also publishes the summed G and the tables
-  const double tr = g_tr, off2 = g_off2;
-  const int sc_exp = (tr > 0.0 && isfinite(tr)) ? __builtin_amdgcn_frexp_exp(tr) : 0;
+  double tr = 0.0, off2 = 0.0;
+  int sc_exp = 0;
+  auto scale_phase = [&]() {
+    block_sum3<1>(g_tr, g_dg2, g_off2, k.dRed);            // its barrier also publishes the summed G and the tables
+    tr = g_tr; off2 = g_off2;
+    sc_exp = (tr > 0.0 && isfinite(tr)) ? __builtin_amdgcn_frexp_exp(tr) : 0;
+    for (int i = wave_u; i < ne; i += NT >> 6)
+      for (int j = tid & 63; j < ne; j += 64) G0[i * ne + j] = __builtin_amdgcn_ldexp(G0[i * ne + j], -sc_exp);
+    lds_barrier();
+  };
+  scale_phase();
   const bool chol_possible = p.chol_thr > 0.0 && n > 4;   // tiny matrices (chain ends, reference policy): never worth it
-  for (int i = wave_u; i < ne; i += NT >> 6)
-    for (int j = tid & 63; j < ne; j += 64) G0[i * ne + j] = __builtin_amdgcn_ldexp(G0[i * ne + j], -sc_exp);
-  lds_barrier();
+
+  // ---- thread roles of the Jacobi iterations (phase 7; the float32 stage of phase 7a uses the same ones) ------------
+  constexpr int kVR = 2;                                 // register blocks per V lane (upper bound); vr of them are used:
+  const int gpw = 64 / np;                               // groups of np lanes per V wave (np <= 32)
+  // one block per lane when the V and G waves then still fit the workgroup (n <= 40: 7 + 4 of 15), two otherwise
+  const int vr = ((np + gpw - 1) / gpw + (np * (np + 1) / 2 + 127) / 128 <= (NT >> 6) - 1) ? 1 : 2;
+  const int NVW = (np + vr * gpw - 1) / (vr * gpw);      // V waves
+  // worker waves = every wave but wave 0 (the parameter wave).  (Measured, round 2: once the parameter chain runs in float32
+  // the round is bound by the float64 issue rate of the working waves; keeping wave 0's SIMD free of them does not pay.)
+  const int nwork = (NT >> 6) - 1, wrank = wave_u - 1;
+  // threads that own G items: as few waves as hold them at one item per lane (np(np+1)/2 = 210 items at n = 40: 4 waves, not
+  // the 8 that are left) -- a round is bound by the float64 issue slots the worker waves share per SIMD, and a wave costs
+  // its slots whatever the number of active lanes
+  const int nGw = min(nwork - NVW, (np * (np + 1) / 2 + 63) / 64);
+  const int NW = nGw * 64;
+  const int gtid = (wrank - NVW) * 64 + (tid & 63);      // index among them (negative: not a G wave)
+  const int vlane = tid & 63, vgrp = vlane / np, vQ = vlane - vgrp * np;
+  const bool isVwave = wrank >= 0 && wrank < NVW;
+  const int vP0 = (wrank * gpw + vgrp) * vr;
+  const bool vLaneOk = isVwave && vgrp < gpw;
+  // G items: the np(np+1)/2 blocks P <= Q of the symmetric G (only entries with row <= column are kept
+  // up to date); at most 2 per worker thread (np <= 32: 528 items on >= 448 threads)
+  constexpr int MAXI = 2;
+  const int nG = np * (np + 1) / 2;
+  bool itValid[MAXI], itDiag[MAXI];
+  int itSrc[MAXI], itCsQ[MAXI], itCsP[MAXI], itD11[MAXI], itD12[MAXI], itD21[MAXI], itD22[MAXI];
+#pragma unroll
+  for (int u = 0; u < MAXI; ++u) {
+    const int it = gtid + u * NW;
+    itValid[u] = wrank >= NVW && gtid < NW && it < nG;
+    int P = 0, Q = 0;
+    if (itValid[u]) {                         // it-th pair (P <= Q) in row-major order of the upper triangle
+      int rem = it;
+      while (rem >= np - P) { rem -= np - P; ++P; }
+      Q = P + rem;
+    }
+    const int c1 = k.sPi[2 * Q], c2 = k.sPi[2 * Q + 1];
+    const int o1 = k.sPi[2 * P], o2 = k.sPi[2 * P + 1];
+    itSrc[u] = (2 * P) * ne + 2 * Q;
+    itCsQ[u] = 4 * Q; itCsP[u] = 4 * P;
+    itDiag[u] = P == Q;
+    // every element lands at (min, max) of its new position
+    itD11[u] = min(o1, c1) * ne + max(o1, c1); itD12[u] = min(o1, c2) * ne + max(o1, c2);
+    itD21[u] = min(o2, c1) * ne + max(o2, c1); itD22[u] = min(o2, c2) * ne + max(o2, c2);
+  }
+  const double abs2 = kJacobiAbs * kJacobiAbs;      // trace is ~1 after scaling
+  // parameter-thread constants
+  const bool isParam = tid < np;
+  int pa = 0, pb = 1;
+  if (isParam) { pa = k.sPiInv[2 * tid]; pb = k.sPiInv[2 * tid + 1]; }
+  const int pA = pa >> 1, ra = pa & 1, pB = pb >> 1, rb = pb & 1;
+  // element offsets of the parameter thread's reads, formed once: left inline they are eight 32-bit multiplies per round on
+  // the critical chain of the parameter wave (v_mul_lo_u32 issues at quarter rate)
+  const int oAd = (2 * pA) * ne + 2 * pA, oAb = (2 * pA + 1) * ne + 2 * pA + 1;
+  const int oBd = (2 * pB) * ne + 2 * pB, oBb = (2 * pB + 1) * ne + 2 * pB + 1;
+  const int oR0 = pA <= pB ? (2 * pA) * ne + 2 * pB : (2 * pB) * ne + 2 * pA, oR1 = oR0 + ne;   // stored block (min, max)
+
+  if (p.stamps && tid == 0) t_c1 = __builtin_amdgcn_s_memtime();
+  // ---- phase 7a: mixed-precision eigen-decomposition (round 3) -------------------------------------------------------
+  // A float64 Jacobi round is a chain of dependent float64 operations (40 cycles each on gfx950): ~1100 cycles, 70 rounds
+  // per decomposition once the chain has settled, 220 on a fresh network.  The same round in float32 is bound by the LDS
+  // round trip of its one barrier.  So:
+  //   (1) two-sided Jacobi on float(G), V32 in float32 registers, same tournament, same look-ahead parameter wave, same
+  //       sliding-window stop: V32 diagonalises G to float32 accuracy and is orthogonal to ~1e-5;
+  //   (2) float64, on the matrix cores: K = V32^T G V32 and E = V32^T V32 - I.  With Z orthonormalising the basis to first
+  //       order in E and rotating every pair that still violates the convergence criterion by its exact 2x2 Jacobi angle,
+  //       all pairs AT ONCE,      Z = I + Y + Y^2 / 2,   Y = X - E / 2,   X[p][q] = -X[q][p] = t_pq,
+  //       G' = Z^T K Z is similar to G up to O(E X, X^4) and its off-diagonals are the square of the old ones (every 2x2 angle
+  //       is tiny after (1): first-order perturbation theory, with the Jacobi formula instead of g / gap so that a close pair
+  //       is still rotated correctly); V = V32 Z.  The criterion is checked on G' and the step repeated if needed (1.0-1.5
+  //       steps on merged tensors of training runs, tests/emulation/jacobi_mixed_emulation.py).
+  // Pairs of two DISCARDED directions are left alone: float32 cannot resolve eigenvalues below ~1e-7 of the largest, their
+  // 2x2 angles are of order one, and nothing that is kept depends on them (kept singular values: relative error ~1e-10;
+  // discarded ones are Rayleigh quotients, good to ~1e-4 sigma_max).  A kept pair that needs a large angle (|t| > kMixedMaxT:
+  // two kept eigenvalues closer than float32 resolves) or a third repetition sends the decomposition down the float64
+  // iteration below (the Gram matrix is formed again).  Adaptive truncation, which reads the whole spectrum, and matrices
+  // below kMixedMinN always take the float64 iteration.
+  const double *Gfin = nullptr;            // diag = eigenvalues / 2^sc_exp
+  double *Vfin = nullptr;                  // eigenvectors, [row][column position]
+  bool mixed_done = false;
+  int rounds32 = 0, refine_its = 0;
+  const bool try_mixed = p.mixed_svd && n >= kMixedMinN && !(p.trunc_thr > 0.0);
+  if (try_mixed) {
+    double *bA = G0, *bB = G1, *bC = V0, *bD = k.Z + 3 * ne * ne;
+    float *F0 = reinterpret_cast<float *>(bB), *F1 = F0 + ne * ne;
+    for (int i = wave_u; i < ne; i += NT >> 6)
+      for (int j = tid & 63; j < ne; j += 64) F0[i * ne + j] = (float)G0[i * ne + j];
+    float4 *cs32 = reinterpret_cast<float4 *>(k.dCS);            // [2][np]: (c, s, t, -) of every pair, two rounds in flight
+    float vf[kVR][4];
+#pragma unroll
+    for (int r = 0; r < kVR; ++r) {
+      const float one = (vP0 + r == vQ) ? 1.f : 0.f;
+      vf[r][0] = one; vf[r][1] = 0.f; vf[r][2] = 0.f; vf[r][3] = one;
+    }
+    float *Fc = F0, *Fn = F1;
+    int cur32 = 0, last_big32 = 0;
+    float kept2f = 0.f;
+    const float big32 = fminf(fmaxf((float)p.svd_stop2, 1e-7f), 1e-3f), abs2f = 1e-30f;
+    auto kept_scale32 = [&](const float *F) -> float {            // as kept_scale below, on the float32 matrix; ends with a barrier
+      const int i = tid & 63;
+      const float li = i < n ? F[i * ne + i] : 0.f;
+      for (int j = wave_u; j < n; j += NT >> 6) {
+        const float lj = F[j * ne + j];
+        const int rank = __popcll(__ballot(i < n && ((li > lj) || (li == lj && i < j))));
+        if (i == 0 && rank == m - 1) k.dRed[60] = (double)lj;
+      }
+      lds_barrier();
+      const float lm = (float)kKeptFrac * fmaxf((float)k.dRed[60], 0.f);
+      return fmaxf(lm * lm, 1e-36f);
+    };
+    auto publish32 = [&](float4 *o, const RotT &r, int applied) {
+      *o = make_float4(r.c0, r.t * r.c0, r.t, 0.f);
+      if (r.level >= 2) k.sFlag[6 + (applied & 1)] = applied + 1;
+    };
+    auto round32 = [&]() {
+      const float4 *csc = cs32 + cur32 * np;
+      const int big_slot = k.sFlag[6 + (rounds32 & 1)];           // consumed after this round's barrier
+      if (isParam) {
+        // look-ahead: pair `tid` of the NEXT round is (a, b) in today's positions; its three elements after today's rotations
+        const float4 cA = csc[pA], cB = csc[pB];
+        const float2 dA = *reinterpret_cast<const float2 *>(Fc + oAd);
+        const float bAe = Fc[oAb];
+        const float2 dB = *reinterpret_cast<const float2 *>(Fc + oBd);
+        const float bBe = Fc[oBb];
+        float2 r0, r1;                                            // rows of block (A, B)
+        if (pA < pB) {
+          r0 = *reinterpret_cast<const float2 *>(Fc + oR0);
+          r1 = *reinterpret_cast<const float2 *>(Fc + oR1);
+        } else if (pA > pB) {                                     // stored as (B, A): transpose
+          const float2 s0 = *reinterpret_cast<const float2 *>(Fc + oR0);
+          const float2 s1 = *reinterpret_cast<const float2 *>(Fc + oR1);
+          r0 = make_float2(s0.x, s1.x);
+          r1 = make_float2(s0.y, s1.y);
+        } else {                                                  // n == 2: the pair meets itself again
+          r0 = dA;
+          r1 = make_float2(dA.y, bAe);
+        }
+        const float na = ra ? fmaf(cA.z, dA.y, bAe) : fmaf(-cA.z, dA.y, dA.x);
+        const float nb = rb ? fmaf(cB.z, dB.y, bBe) : fmaf(-cB.z, dB.y, dB.x);
+        const float h0 = ra ? fmaf(cA.y, r0.x, cA.x * r1.x) : fmaf(cA.x, r0.x, -cA.y * r1.x);
+        const float h1 = ra ? fmaf(cA.y, r0.y, cA.x * r1.y) : fmaf(cA.x, r0.y, -cA.y * r1.y);
+        const float ng = rb ? fmaf(cB.y, h0, cB.x * h1) : fmaf(cB.x, h0, -cB.y * h1);
+        publish32(cs32 + (cur32 ^ 1) * np + tid, jacobi_rot_f32(na, nb, ng, kept2f, abs2f, big32), rounds32 + 1);
+      }
+      if (isVwave) {                                              // whole waves: every lane runs the shifts
+        const float4 q4 = csc[vLaneOk ? vQ : 0];
+#pragma unroll
+        for (int r = 0; r < kVR; ++r) {
+          if (r >= vr) break;                                     // wave-uniform
+          // columns by R_Q: (v1, v2) -> (c v1 - s v2, s v1 + c v2)
+          const float n11 = fmaf(q4.x, vf[r][0], -q4.y * vf[r][1]), n12 = fmaf(q4.y, vf[r][0], q4.x * vf[r][1]);
+          const float n21 = fmaf(q4.x, vf[r][2], -q4.y * vf[r][3]), n22 = fmaf(q4.y, vf[r][2], q4.x * vf[r][3]);
+          if (np > 1) {
+            const float t1 = dpp_f32<0x138>(n11), t2 = dpp_f32<0x138>(n21);      // top column of pair Q-1
+            const float b1 = dpp_f32<0x138>(n12), b2 = dpp_f32<0x138>(n22);      // bottom column of pair Q-1
+            const float c1 = dpp_f32<0x130>(n12), c2 = dpp_f32<0x130>(n22);      // bottom column of pair Q+1
+            vf[r][0] = vQ == 0 ? n11 : (vQ == 1 ? b1 : t1);
+            vf[r][2] = vQ == 0 ? n21 : (vQ == 1 ? b2 : t2);
+            vf[r][1] = vQ == np - 1 ? n11 : c1;
+            vf[r][3] = vQ == np - 1 ? n21 : c2;
+          } else {
+            vf[r][0] = n11; vf[r][1] = n12; vf[r][2] = n21; vf[r][3] = n22;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < MAXI; ++u) {
+        if (!itValid[u]) continue;
+        const float4 q4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(csc) + itCsQ[u]);   // column pair
+        const float4 p4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(csc) + itCsP[u]);   // row pair
+        const float *src = Fc + itSrc[u];
+        const float2 r0 = *reinterpret_cast<const float2 *>(src);
+        float2 r1 = *reinterpret_cast<const float2 *>(src + ne);
+        if (itDiag[u]) r1.x = r0.y;                               // lower element of a diagonal block = its mirror
+        // R_P^T . blk . R_Q,  R = [[c, s], [-s, c]]
+        const float a11 = fmaf(p4.x, r0.x, -p4.y * r1.x), a12 = fmaf(p4.x, r0.y, -p4.y * r1.y);
+        const float a21 = fmaf(p4.y, r0.x, p4.x * r1.x), a22 = fmaf(p4.y, r0.y, p4.x * r1.y);
+        float n11 = fmaf(q4.x, a11, -q4.y * a12), n12 = fmaf(q4.y, a11, q4.x * a12);
+        float n21 = fmaf(q4.x, a21, -q4.y * a22), n22 = fmaf(q4.y, a21, q4.x * a22);
+        if (itDiag[u] && q4.z != 0.f) {                           // the annihilated element exactly, the diagonal in its stable form
+          n12 = 0.f; n21 = 0.f;
+          n11 = fmaf(-q4.z, r0.y, r0.x); n22 = fmaf(q4.z, r0.y, r1.y);
+        }
+        Fn[itD11[u]] = n11; Fn[itD12[u]] = n12;
+        if (!itDiag[u]) Fn[itD21[u]] = n21;
+        Fn[itD22[u]] = n22;
+      }
+      lds_barrier();
+      float *tsw = Fc; Fc = Fn; Fn = tsw;
+      cur32 ^= 1;
+      last_big32 = max(last_big32, big_slot);
+      ++rounds32;
+    };
+    lds_barrier();                                                // float(G) complete
+    kept2f = kept_scale32(Fc);
+    if (tid == 0) { k.sFlag[6] = 0; k.sFlag[7] = 0; }
+    if (isParam) {                                                // rotations of the very first round
+      const float2 top = *reinterpret_cast<const float2 *>(Fc + (2 * tid) * ne + 2 * tid);
+      publish32(cs32 + cur32 * np + tid, jacobi_rot_f32(top.x, Fc[(2 * tid + 1) * ne + 2 * tid + 1], top.y, kept2f, abs2f, big32), 0);
+    }
+    lds_barrier();
+    bool conv32 = false;
+    for (int sw32 = 0; sw32 < kMixedMaxSweeps && !conv32; ++sw32) {
+      for (int rnd = 0; rnd < ne - 1; ++rnd) {
+        round32();
+        if (rounds32 - __builtin_amdgcn_readfirstlane(last_big32) >= ne - 1) { conv32 = true; break; }
+      }
+      if (!conv32) kept2f = kept_scale32(Fc);
+    }
+    // V32 leaves the registers as float64 numbers: [row][column position]
+    if (vLaneOk) {
+#pragma unroll
+      for (int r = 0; r < kVR; ++r) {
+        const int P = vP0 + r;
+        if (r < vr && P < np) {
+          *reinterpret_cast<double2 *>(bC + (2 * P) * ne + 2 * vQ) = make_double2((double)vf[r][0], (double)vf[r][1]);
+          *reinterpret_cast<double2 *>(bC + (2 * P + 1) * ne + 2 * vQ) = make_double2((double)vf[r][2], (double)vf[r][3]);
+        }
+      }
+    }
+    lds_barrier();
+    // level 1: H0 = G V32 -> bD,  E = V32^T V32 - I -> float32 in bB (the float32 matrices of stage (1) are dead)
+    {
+      float *E32 = reinterpret_cast<float *>(bB);
+      const int slot = mm_lds(1, ne, ne, ne, bA, 0, ne, 1, bC, 0, ne, 1, [&](int, int i, int j, double v) { bD[i * ne + j] = v; });
+      mm_lds(1, ne, ne, ne, bC, 0, 1, ne, bC, 0, ne, 1,
+             [&](int, int i, int j, double v) {
+               if (i <= j) { const float e = (float)(v - (i == j ? 1.0 : 0.0)); E32[i * ne + j] = e; E32[j * ne + i] = e; }
+             }, true, slot);
+    }
+    lds_barrier();
+    // level 2: K = V32^T H0 -> bA (G is dead), both triangles from the upper one
+    mm_lds(1, ne, ne, ne, bC, 0, 1, ne, bD, 0, ne, 1,
+           [&](int, int i, int j, double v) { if (i <= j) { bA[i * ne + j] = v; bA[j * ne + i] = v; } }, true);
+    lds_barrier();
+    const double final2 = p.svd_stop2 * p.svd_stop2;
+    bool failed = false;
+    for (int it = 0;; ++it) {
+      const bool first = it == 0;                                 // E is folded into the first step only
+      const float *E32 = reinterpret_cast<const float *>(bB);
+      float *Y32 = reinterpret_cast<float *>(bB) + ne * ne;
+      // diagonal in the orthonormalised basis, ranks, kept set
+      for (int i = tid; i < ne; i += NT) k.dLam[i] = bA[i * ne + i] * (1.0 - (first ? (double)E32[i * ne + i] : 0.0));
+      if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
+      lds_barrier();
+      {
+        const int i = tid & 63;
+        const double li = i < n ? k.dLam[i] : 0.0;
+        for (int j = wave_u; j < n; j += NT >> 6) {
+          const double lj = k.dLam[j];
+          const int rank = __popcll(__ballot(i < n && ((li > lj) || (li == lj && i < j))));
+          if (i == 0) { k.sOrd[j] = rank; if (rank == m - 1) k.dRed[60] = lj; }
+        }
+      }
+      lds_barrier();
+      const double lmk = kKeptFrac * fmax(k.dRed[60], 0.0), kept2d = lmk * lmk;
+      float mx_rel = 0.f, mx_t = 0.f;
+      for (int i = wave_u; i < ne; i += NT >> 6)
+        for (int j = tid & 63; j < ne; j += 64) {
+          if (i < j) {
+            const double di = k.dLam[i], dj = k.dLam[j];
+            const float e = first ? E32[i * ne + j] : 0.f;
+            const double g = bA[i * ne + j] - 0.5 * (double)e * (di + dj);
+            const bool kp = i < n && j < n && (k.sOrd[i] < m || k.sOrd[j] < m);
+            const double sc = fmax(fabs(di * dj), kept2d), g2 = g * g;
+            float t = 0.f;
+            if (kp && g2 > fmax(final2 * sc, abs2)) {
+              const float df = (float)(dj - di), gf = (float)g;
+              const float hyp = __builtin_amdgcn_sqrtf(fmaf(df, df, 4.f * gf * gf));
+              const float den = df + copysignf(hyp, df);
+              t = den != 0.f ? 2.f * gf * __builtin_amdgcn_rcpf(den) : 0.f;
+              mx_rel = fmaxf(mx_rel, (float)(g2 / sc));
+              mx_t = fmaxf(mx_t, fabsf(t));
+            }
+            Y32[i * ne + j] = t - 0.5f * e;
+            Y32[j * ne + i] = -t - 0.5f * e;
+          } else if (i == j) {
+            Y32[i * ne + i] = first ? -0.5f * E32[i * ne + i] : 0.f;
+          }
+        }
+      mx_rel = wave_max_f32(mx_rel); mx_t = wave_max_f32(mx_t);
+      if ((tid & 63) == 0) {                                      // non-negative floats order like their bit patterns
+        atomicMax(reinterpret_cast<unsigned *>(k.sFlag), __float_as_uint(mx_rel));
+        atomicMax(reinterpret_cast<unsigned *>(k.sFlag) + 1, __float_as_uint(mx_t));
+      }
+      lds_barrier();
+      const unsigned urel = __builtin_amdgcn_readfirstlane(k.sFlag[0]), ut = __builtin_amdgcn_readfirstlane(k.sFlag[1]);
+      if (!first && urel == 0u) break;                            // every kept pair meets the criterion
+      if (__uint_as_float(ut) > kMixedMaxT || it >= kMixedMaxIt) { failed = true; break; }
+      // Z = I + Y + Y^2 / 2 -> bD
+      mm_lds(1, ne, ne, ne, Y32, 0, ne, 1, Y32, 0, ne, 1,
+             [&](int, int i, int j, double v) { bD[i * ne + j] = 0.5 * v + (double)Y32[i * ne + j] + (i == j ? 1.0 : 0.0); });
+      lds_barrier();
+      // H = K Z -> bB (E and Y are dead)
+      mm_lds(1, ne, ne, ne, bA, 0, ne, 1, bD, 0, ne, 1, [&](int, int i, int j, double v) { bB[i * ne + j] = v; });
+      lds_barrier();
+      // K' = Z^T H -> bA
+      mm_lds(1, ne, ne, ne, bD, 0, 1, ne, bB, 0, ne, 1,
+             [&](int, int i, int j, double v) { if (i <= j) { bA[i * ne + j] = v; bA[j * ne + i] = v; } }, true);
+      lds_barrier();
+      // V' = V Z -> bB, which becomes the basis; the old basis buffer is the scratch of the next step
+      mm_lds(1, ne, ne, ne, bC, 0, ne, 1, bD, 0, ne, 1, [&](int, int i, int j, double v) { bB[i * ne + j] = v; });
+      lds_barrier();
+      double *tsw = bB; bB = bC; bC = tsw;
+      ++refine_its;
+    }
+    if (!failed) {
+      mixed_done = true;
+      Gfin = bA; Vfin = bC;
+    } else {
+      gram_phase();                                               // the float64 iteration starts from G again
+      scale_phase();
+    }
+  }
 
   // ---- phase 6b: one pivoted-Cholesky step when G is far from diagonal ------------------------------------------
   // G = L L^T (diagonal pivoting), G' = L^T L has the same eigenvalues and is graded: the Jacobi iteration then needs
@@ -680,8 +909,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // neutral in the steady state and +2 % cold)
   const double cthr = n >= 32 ? p.chol_thr : fmax(p.chol_thr, kCholThrSmall);
   // (block-uniform: every thread holds the same sums; told to the compiler so that the step below is scalar control flow)
-  const bool use_chol = __builtin_amdgcn_readfirstlane((int)(chol_possible && off2 > cthr * cthr * tr * tr)) != 0;
-  XSTAMP(5);
+  const bool use_chol = __builtin_amdgcn_readfirstlane((int)(!mixed_done && chol_possible && off2 > cthr * cthr * tr * tr)) != 0;
   if (use_chol) {
     for (int e = tid; e < ne * ne; e += NT) Lm[e] = 0.0;
     // The factorisation is bound by LDS traffic, so a worker thread (waves 1..15) owns up to kCholPer fixed PAIRS of
@@ -742,7 +970,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       }
     }
     lds_barrier();
-    XSTAMP(6);
     // G' = L^T L into G0 (the trailing matrix is dead)
     mm_lds(1, n, n, n, Lm, 0, ne, 1, Lm, 0, 1, ne, [&](int, int a, int b, double v) { G0[a * ne + b] = v; });
     lds_barrier();
@@ -751,7 +978,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     lds_barrier();
   }
 
-  XSTAMP(7);
   // ---- phase 7: two-sided Jacobi, ONE barrier per round ----------------------------------------------
   // Workers (tid >= 64) own one 2x2 block of G and one of V per item: rows by R_P^T, columns by R_Q,
   // written into the other buffer at the next round's positions.  Meanwhile parameter thread k
@@ -764,24 +990,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   //   column pair Q = its lane within a group of np lanes) in registers; the column rotation is local and
   //   the tournament move (top element of pair Q -> pair Q+1, bottom element -> pair Q-1) is a one-lane
   //   wave shift (DPP wave_shr / wave_shl, tools/ubench/dpp_wave_shift.hip).
-  constexpr int kVR = 2;                                 // register blocks per V lane (upper bound); vr of them are used:
-  const int gpw = 64 / np;                               // groups of np lanes per V wave (np <= 32)
-  // one block per lane when the V and G waves then still fit the workgroup (n <= 40: 7 + 4 of 15), two otherwise
-  const int vr = ((np + gpw - 1) / gpw + (np * (np + 1) / 2 + 127) / 128 <= (NT >> 6) - 1) ? 1 : 2;
-  const int NVW = (np + vr * gpw - 1) / (vr * gpw);      // V waves
-  // worker waves = every wave but wave 0 (the parameter wave).  (Measured, round 2: once the parameter chain runs in float32
-  // the round is bound by the float64 issue rate of the working waves; keeping wave 0's SIMD free of them does not pay.)
-  const int nwork = (NT >> 6) - 1, wrank = wave_u - 1;
-  // threads that own G items: as few waves as hold them at one item per lane (np(np+1)/2 = 210 items at n = 40: 4 waves, not
-  // the 8 that are left) -- a round is bound by the float64 issue slots the worker waves share per SIMD, and a wave costs
-  // its slots whatever the number of active lanes
-  const int nGw = min(nwork - NVW, (np * (np + 1) / 2 + 63) / 64);
-  const int NW = nGw * 64;
-  const int gtid = (wrank - NVW) * 64 + (tid & 63);      // index among them (negative: not a G wave)
-  const int vlane = tid & 63, vgrp = vlane / np, vQ = vlane - vgrp * np;
-  const bool isVwave = wrank >= 0 && wrank < NVW;
-  const int vP0 = (wrank * gpw + vgrp) * vr;
-  const bool vLaneOk = isVwave && vgrp < gpw;
   double vb[kVR][4];                                     // {v11, v12, v21, v22} per block
 #pragma unroll
   for (int r = 0; r < kVR; ++r) {
@@ -790,43 +998,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   }
   int sweeps = 0, converged = 0;
   double *Gc = G0, *Gn = G1;
-  // G items: the np(np+1)/2 blocks P <= Q of the symmetric G (only entries with row <= column are kept
-  // up to date); at most 2 per worker thread (np <= 32: 528 items on >= 448 threads)
-  constexpr int MAXI = 2;
-  const int nG = np * (np + 1) / 2;
-  bool itValid[MAXI], itDiag[MAXI];
-  int itSrc[MAXI], itCsQ[MAXI], itCsP[MAXI], itD11[MAXI], itD12[MAXI], itD21[MAXI], itD22[MAXI];
-#pragma unroll
-  for (int u = 0; u < MAXI; ++u) {
-    const int it = gtid + u * NW;
-    itValid[u] = wrank >= NVW && gtid < NW && it < nG;
-    int P = 0, Q = 0;
-    if (itValid[u]) {                         // it-th pair (P <= Q) in row-major order of the upper triangle
-      int rem = it;
-      while (rem >= np - P) { rem -= np - P; ++P; }
-      Q = P + rem;
-    }
-    const int c1 = k.sPi[2 * Q], c2 = k.sPi[2 * Q + 1];
-    const int o1 = k.sPi[2 * P], o2 = k.sPi[2 * P + 1];
-    itSrc[u] = (2 * P) * ne + 2 * Q;
-    itCsQ[u] = 4 * Q; itCsP[u] = 4 * P;
-    itDiag[u] = P == Q;
-    // every element lands at (min, max) of its new position
-    itD11[u] = min(o1, c1) * ne + max(o1, c1); itD12[u] = min(o1, c2) * ne + max(o1, c2);
-    itD21[u] = min(o2, c1) * ne + max(o2, c1); itD22[u] = min(o2, c2) * ne + max(o2, c2);
-  }
-  const double abs2 = kJacobiAbs * kJacobiAbs;      // trace is ~1 after scaling
-  // parameter-thread constants
-  const bool isParam = tid < np;
-  int pa = 0, pb = 1;
-  if (isParam) { pa = k.sPiInv[2 * tid]; pb = k.sPiInv[2 * tid + 1]; }
-  const int pA = pa >> 1, ra = pa & 1, pB = pb >> 1, rb = pb & 1;
-  // element offsets of the parameter thread's reads, formed once: left inline they are eight 32-bit multiplies per round on
-  // the critical chain of the parameter wave (v_mul_lo_u32 issues at quarter rate)
-  const int oAd = (2 * pA) * ne + 2 * pA, oAb = (2 * pA + 1) * ne + 2 * pA + 1;
-  const int oBd = (2 * pB) * ne + 2 * pB, oBb = (2 * pB + 1) * ne + 2 * pB + 1;
-  const int oR0 = pA <= pB ? (2 * pA) * ne + 2 * pB : (2 * pB) * ne + 2 * pA, oR1 = oR0 + ne;   // stored block (min, max)
-
   auto kept_scale = [&](const double *G) -> double {
     // (kKeptFrac * m-th largest diagonal entry)^2, block-wide; ends with a barrier
     const int i = tid & 63;
@@ -843,8 +1014,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 
   int cur = 0;
   double kept2 = 0.0;
-  // one round; xP / xG / xV switch the parameter threads, the G items and the V items (all true except in
-  // the timing experiment at the end of the kernel)
   // Rotation slot of pair k in dCS (4 doubles): [0] t, [1] c0 as doubles (float32-exact values), [2] the same two as a
   // float2 for the look-ahead chain.  See jacobi_rot_f32 (jacobi_device.h) for the arithmetic.
   const float kept_lo = 1e-36f;
@@ -858,12 +1027,10 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     if (r.level >= 2) k.sFlag[6 + (applied & 1)] = applied + 1;
   };
   int round_idx = 0, last_big1 = 0;          // rounds applied so far; 1 + index of the last round with a big rotation
-  auto jacobi_round = [&](const bool stampRound, const bool xP, const bool xG, const bool xV, const bool stampAll = false) {
+  auto jacobi_round = [&]() {
         const double *csc = k.dCS + cur * np * 4;
         const int big_slot = k.sFlag[6 + (round_idx & 1)];      // consumed after this round's barrier
-        unsigned long long r_t0 = 0, r_t1 = 0, r_t2 = 0, r_t3 = 0;
-        if (stampRound) r_t0 = __builtin_amdgcn_s_memtime();
-        if (isParam && xP) {
+        if (isParam) {
           // look-ahead: pair `tid` of the NEXT round is (a, b) in today's positions; its three elements after today's
           // rotations, in float32 (the inputs are read as float64 and converted)
           const float2 fA = *reinterpret_cast<const float2 *>(csc + 4 * pA + 2);     // (t, c0) of pair A
@@ -894,21 +1061,11 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
           const float h0 = ra ? fmaf(sA, q0x, cA * q1x) : fmaf(cA, q0x, -sA * q1x);
           const float h1 = ra ? fmaf(sA, q0y, cA * q1y) : fmaf(cA, q0y, -sA * q1y);
           const float ng = rb ? fmaf(sB, h0, cB * h1) : fmaf(cB, h0, -sB * h1);
-          if (stampRound) { asm volatile("" :: "v"(na), "v"(nb), "v"(ng)); r_t1 = __builtin_amdgcn_s_memtime(); }
           const RotT r = jacobi_rot_f32(na, nb, ng, fmaxf((float)kept2, kept_lo), (float)abs2, (float)p.svd_stop2);
-          if (stampRound) { asm volatile("" :: "v"(r.t), "v"(r.c0)); r_t2 = __builtin_amdgcn_s_memtime(); }
           publish(k.dCS + ((cur ^ 1) * np + tid) * 4, r, round_idx + 1);
         }
-#ifdef TNML_EXP_FINE_STAMPS
-        const bool wst = p.stamps && stampAll && (tid & 63) == 0;
-        unsigned long long w_t0 = 0, w_t1 = 0, w_t2 = 0;
-        if (wst) w_t0 = __builtin_amdgcn_s_memtime();
-#endif
-        if (isVwave && xV) {                                    // whole waves: every lane runs the shifts
+        if (isVwave) {                                    // whole waves: every lane runs the shifts
           const double2 tc = *reinterpret_cast<const double2 *>(csc + 4 * (vLaneOk ? vQ : 0));     // (t, c0) of pair Q
-#ifdef TNML_EXP_FINE_STAMPS
-          if (wst) { asm volatile("" :: "v"(tc.x), "v"(tc.y)); w_t1 = __builtin_amdgcn_s_memtime(); }
-#endif
           const double cq = tc.y * rot_corr(tc.x, tc.y);
 #pragma unroll
           for (int r = 0; r < kVR; ++r) {
@@ -931,16 +1088,13 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
         }
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-          if (!itValid[u] || !xG) continue;
+          if (!itValid[u]) continue;
           const double2 tq = *reinterpret_cast<const double2 *>(csc + itCsQ[u]);      // (t, c0) of the column pair
           const double2 tp = *reinterpret_cast<const double2 *>(csc + itCsP[u]);      // ... of the row pair
           const double *src = Gc + itSrc[u];
           const double2 r0 = *reinterpret_cast<const double2 *>(src);
           double2 r1 = *reinterpret_cast<const double2 *>(src + ne);
           if (itDiag[u]) r1.x = r0.y;                           // lower element of a diagonal block = its mirror
-#ifdef TNML_EXP_FINE_STAMPS
-          if (wst && u == 0) { asm volatile("" :: "v"(r0.x), "v"(r1.y), "v"(tq.x), "v"(tp.y)); w_t1 = __builtin_amdgcn_s_memtime(); }
-#endif
           // R_P^T . blk . R_Q = cP cQ [[1, -tP], [tP, 1]] . blk . [[1, tQ], [-tQ, 1]]: the tangents act first (they need no
           // refinement), the product of the two cosines is formed meanwhile and multiplied in last
           const double a11 = fma(-tp.x, r1.x, r0.x), a12 = fma(-tp.x, r1.y, r0.y);
@@ -954,30 +1108,17 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
           if (!itDiag[u]) Gn[itD21[u]] = n21;                   // (n21 of a diagonal block is n12's mirror)
           Gn[itD22[u]] = n22;
         }
-#ifdef TNML_EXP_FINE_STAMPS
-        if (wst) {
-          asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(vb[0][0]), "v"(vb[1][3]) : "memory");
-          w_t2 = __builtin_amdgcn_s_memtime();
-        }
-#endif
         lds_barrier();
-#ifdef TNML_EXP_FINE_STAMPS
-        if (wst) {
-          const unsigned long long w_t3 = __builtin_amdgcn_s_memtime();
-          p.stamps[56 + 16 + (tid >> 6)] = (double)(w_t2 - w_t0) + 1e-3 * (double)(wrank + 1) + 1e5 * (double)(w_t3 - w_t2);   // work + 1e5 * wait, role in the fraction
-        }
-#endif
-        if (stampRound) {
-          r_t3 = __builtin_amdgcn_s_memtime();
-          p.stamps[14] = (double)(r_t1 - r_t0); p.stamps[15] = (double)(r_t2 - r_t1); p.stamps[16] = (double)(r_t3 - r_t2);
-        }
         double *tsw = Gc; Gc = Gn; Gn = tsw;
         cur ^= 1;
         last_big1 = max(last_big1, big_slot);
         ++round_idx;
   };
-  if (p.stamps && tid == 0) t_c1 = __builtin_amdgcn_s_memtime();
-  if (n > 1) {
+  if (mixed_done) {
+    converged = 1;
+    round_idx = rounds32;
+    sweeps = (rounds32 + ne - 2) / (ne - 1);
+  } else if (n > 1) {
     kept2 = kept_scale(Gc);
     if (tid == 0) { k.sFlag[6] = 0; k.sFlag[7] = 0; }
     if (isParam) {                                   // rotations of the very first round
@@ -993,11 +1134,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     // about a third of a sweep per decomposition once the chain has settled).
     for (; sweeps < kJacobiMaxSweeps && !converged; ++sweeps) {
       for (int rnd = 0; rnd < ne - 1; ++rnd) {
-#ifdef TNML_EXP_FINE_STAMPS
-        jacobi_round(p.stamps && tid == 0 && sweeps == 0 && rnd == 7, true, true, true, sweeps == 0 && rnd == 7);
-#else
-        jacobi_round(false, true, true, true);
-#endif
+        jacobi_round();
         // block-uniform, and told so: the flag word comes out of LDS (a vector register), and a loop exit the compiler has
         // to treat as divergent wraps every round in EXEC-mask bookkeeping
         if (round_idx - __builtin_amdgcn_readfirstlane(last_big1) >= ne - 1) { converged = 1; break; }
@@ -1009,7 +1146,11 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   }
   // the eigenvectors leave the registers: V[row][column position], as phase 9 reads them
   double *V = V0;
-  if (vLaneOk) {
+  if (mixed_done) {
+    V = Vfin;
+    Gc = const_cast<double *>(Gfin);
+    Gn = nullptr;
+  } else if (vLaneOk) {
 #pragma unroll
     for (int r = 0; r < kVR; ++r) {
       const int P = vP0 + r;
@@ -1051,6 +1192,11 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       atomicAdd(p.counters + 1, 1ull);
       atomicAdd(p.counters + 2, (unsigned long long)round_idx);
       if (use_chol) atomicAdd(p.counters + 3, 1ull);
+      if (try_mixed) {                                      // float32 stage taken / simultaneous steps / fell back to float64
+        atomicAdd(p.counters + 8, 1ull);
+        atomicAdd(p.counters + 9, (unsigned long long)refine_its);
+        if (!mixed_done) atomicAdd(p.counters + 10, 1ull);
+      }
     }
     if (!converged) atomicOr(p.status, 2);
     if (p.dbg) {
@@ -1094,7 +1240,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     k.dSq[ne + sp] = ok ? 1.0 / sq : 0.0;
   }
   lds_barrier();
-  YSTAMP(6);
   // short-side factor: q_j * sigma_j^(1/2)   (rows kk over waves, kept columns over lanes: no divisions).  The same pass
   // gathers the kept eigenvectors, scaled by sigma_j^(-1/2), into a dense [n][mk] matrix for the long-side product below
   // (no per-element indirection through the order table there, no scaling in its epilogue)
@@ -1140,18 +1285,15 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 
   if (p.stamps && tid == 0) t_c2c = __builtin_amdgcn_s_memtime();
   // ---- phase 10: behind norm environment of the next step ------------------------------------------
-  YSTAMP(10);
   if (p.Nh_new) {
     if (!short_rows) {
       mm_lds(1, h, DM, h, k.dNh, 0, h, 1, k.sCb, 0, DM, 1, store_T2);
-      YSTAMP(11);
       lds_barrier();
     }
     // Nh_new[s', s''] = sum_{(h_, d)} Cb[(h_, d), s'] T2[(h_, d), s'']
     mm_lds(1, mk, mk, h * D, k.sCb, 0, 1, mk, k.dT2, 0, mk, 1,
            [&](int, int i, int j, double v) { p.Nh_new[i * mk + j] = v; });
   }
-  YSTAMP(12);
 
   if (p.stamps && tid == 0) {
     // diagnostic stamps: shader cycles before / in / after the Jacobi loop and the 100 MHz real-time
@@ -1162,20 +1304,9 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     p.stamps[3] = (double)(t_r3 - t_r0); p.stamps[4] = (double)sweeps; p.stamps[5] = (double)n;
     p.stamps[50] = (double)round_idx;                 // rounds actually run (the sliding window stops inside a sweep)
     for (int i = 0; i < 5; ++i) p.stamps[9 + i] = (double)(t_p[i] - (i ? t_p[i - 1] : t_c0));
-#ifdef TNML_EXP_FINE_STAMPS
-    p.stamps[34] = (double)(t_x[0] - t_p[2]); p.stamps[35] = (double)(t_x[1] - t_x[0]); p.stamps[36] = (double)(t_x[2] - t_x[1]);
-    p.stamps[37] = (double)(t_p[3] - t_x[2]); p.stamps[38] = (double)(t_x[3] - t_p[3]); p.stamps[39] = (double)(t_x[4] - t_x[3]);
-    p.stamps[40] = (double)(t_p[4] - t_x[4]);
-    p.stamps[48] = use_chol ? (double)(t_x[6] - t_x[5]) : 0.0; p.stamps[49] = use_chol ? (double)(t_x[7] - t_x[6]) : 0.0;
-    for (int i = 0; i < 16; ++i) p.stamps[56 + i] = t_y[i] ? (double)(t_y[i] - t_c0) : 0.0;      // cycles since the kernel's start
-#endif
     p.stamps[6] = (double)(t_c2b - t_c2); p.stamps[7] = (double)(t_c2c - t_c2b); p.stamps[8] = (double)(t_c3 - t_c2c);
   }
 
-#if defined(TNML_EXP_FINE_STAMPS) && !defined(TNML_EXP_HELPER_WAVES)
-  if (p.stamps && (tid & 63) == 0)
-    for (int i = 0; i < 12; ++i) p.stamps[115 + (tid >> 6) * 12 + i] = (double)(t_w[i] & ((1ull << 44) - 1));
-#endif
   // ---- phase 11: metrics of this step (var_hist, Network_class.py:739-750) --------------------------
   if (tid == 0 && p.metrics) {
     const double cnt = (double)ldtail(3);
@@ -1184,24 +1315,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     p.metrics[1] = (float)((double)ldtail(1) * inv / (double)L);
     if (ldtail(2) != 0.f) atomicOr(p.status, 1);
   }
-#ifdef TNML_EXP_ROUND_TIMING
-  // timing experiment (tools/build_exp.sh): ne-1 rounds each with parts of the round switched off, on the
-  // dead Jacobi buffers; cycles per round land in stamps[41..47]
-  if (p.stamps && n > 2) {
-    lds_barrier();
-    for (int variant = 0; variant < 7; ++variant) {
-      // bit 0: parameter threads, bit 1: G items, bit 2: V blocks
-      const int mask = variant == 0 ? 7 : variant;          // 0 -> everything; 1 P; 2 G; 3 P+G; 4 V; 5 P+V; 6 G+V
-      const bool xP = mask & 1, xG = mask & 2, xV = mask & 4;
-      lds_barrier();
-      const unsigned long long e0 = __builtin_amdgcn_s_memtime();
-      for (int rnd = 0; rnd < ne - 1; ++rnd) jacobi_round(false, xP, xG, xV);
-      const unsigned long long e1 = __builtin_amdgcn_s_memtime();
-      if (tid == 0) p.stamps[41 + variant] = (double)(e1 - e0) / (double)(ne - 1);
-    }
-    if (vLaneOk) for (int r = 0; r < kVR; ++r) for (int q = 0; q < 4; ++q) V0[(vP0 + r) * 4 + q] += vb[r][q];   // keep V alive
-  }
-#endif
 }
 
 // classic step: one narrow launch (workgroup 0 + optional reduce / slice helpers)

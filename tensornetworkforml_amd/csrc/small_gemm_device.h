@@ -201,17 +201,10 @@ __device__ inline void mm_lds_f32(int M, int N, int K, const float *A, int a_rs,
 // ------------------------------------------------------------------------------------------
 // coherent: the results are read by another workgroup of the SAME launch (agent-scope stores; see narrow_helper_block)
 __device__ inline void prep_slice_block(const PrepParams &p, int slice, unsigned char *smem_raw, bool coherent = false, double *hstamp = nullptr) {
-#define HSTAMP(i) if (hstamp && threadIdx.x == 0) hstamp[i] = (double)(__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1))
-#ifdef TNML_EXP_HELPER_WAVES   // per-wave shader-cycle stamps of the helper's phases into the probe area (hstamp + 27 = stamps[115])
-#define HWAVE(i) if (hstamp && (threadIdx.x & 63) == 0) hstamp[27 + (threadIdx.x >> 6) * 12 + (i)] = (double)(__builtin_amdgcn_s_memtime() & ((1ull << 44) - 1))
-#else
-#define HWAVE(i)
-#endif
   // B_dd' = lab_d . pl_d'   and   (Ln.B.Rn)_dd' = (Nh^T lab_d) . (pl_d' Ng): the three first-level products are independent
   // and run back to back without a barrier, the second level is one more product -- a dependent chain of two instead of
   // three, behind ONE round trip to memory for all four operands.
   const int tid = threadIdx.x, NT = blockDim.x;
-  HSTAMP(0);
   const int D = kD, h = p.h, g = p.g, s = p.s, L = p.L;
   // rows [i_lo, i_lo + nr) of slice (dk, dk1): a slice may be cut into row parts over several workgroups (a 20-row slice is
   // 16 + 4 rows of MFMA tiles anyway), which only repeat the small product pl . Ng
@@ -256,7 +249,6 @@ __device__ inline void prep_slice_block(const PrepParams &p, int slice, unsigned
       if (p.l2_flag && e < nhh) dNh[e] = rh[u];
       if (p.l2_flag && e < ngg) dNg[e] = rg[u];
     }
-    HSTAMP(1);
     for (int e = tid + 2 * NT; e < nlab; e += NT) sLab[e] = lab_at(e);
     for (int e = tid + 2 * NT; e < npl; e += NT) sPl[e] = pl_at(e);
     if (p.l2_flag) {
@@ -265,8 +257,6 @@ __device__ inline void prep_slice_block(const PrepParams &p, int slice, unsigned
     }
   }
   __syncthreads();
-  HSTAMP(2);
-  HWAVE(0);
   // Results leave through LDS: a row (i) of a slice is g * L contiguous elements of the [h][dk][dk1][g][l] layout, so the
   // hand-off to another workgroup of this launch goes out as 16-byte agent-scope stores instead of one fabric write per element.
   const int gL = g * L;
@@ -280,17 +270,12 @@ __device__ inline void prep_slice_block(const PrepParams &p, int slice, unsigned
                         if (coherent) __hip_atomic_store(dst, (float)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = (float)v;
                       }
                     });
-  HWAVE(1);
   if (p.l2_flag) {
     // X[i][x] = sum_a Nh[a][i] lab[a][x]  (x = (s_, l));   Y[s_][j] = sum_c pl[s_][c] Ng[c][j]
     slot = mm_lds(1, nr, sL, h, dNh + i_lo, 0, 1, h, sLab, 0, sL, 1, [&](int, int i, int x, double v) { dX[i * sL + x] = v; }, false, slot);
     mm_lds(1, s, g, g, sPl, 0, g, 1, dNg, 0, g, 1, [&](int, int s_, int j, double v) { dY[s_ * g + j] = v; }, false, slot);
   }
-  HSTAMP(3);
-  HWAVE(2);
   __syncthreads();
-  HSTAMP(4);
-  HWAVE(3);
   if (vecB) {                                            // B rows: (gL / 4) 16-byte pieces each
     const __amdgpu_buffer_rsrc_t rB = sc1_rsrc(p.prepB);
     const int pieces = gL >> 2, total = nr * pieces;
@@ -311,8 +296,6 @@ __device__ inline void prep_slice_block(const PrepParams &p, int slice, unsigned
                if (coherent) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = v;
              }
            });
-    HSTAMP(5);
-    HWAVE(4);
     if (vecG) {
       __syncthreads();
       const __amdgpu_buffer_rsrc_t rG = sc1_rsrc(p.prepG);
@@ -325,10 +308,6 @@ __device__ inline void prep_slice_block(const PrepParams &p, int slice, unsigned
       }
     }
   }
-  HSTAMP(6);
-  HWAVE(5);
-#undef HSTAMP
-#undef HWAVE
 }
 
 // LDS bytes prep_slice_block needs

@@ -67,6 +67,7 @@ struct tnml_ctx {
   bool check_launches = false;               // tnml_debug_enable bit 2: read the launch status back after every kernel launch
   int sync_interval = 0;                     // tnml_set_sync_interval: drain the stream every so many steps (0 = never)
   double svd_stop2 = kSvdStop2Default;
+  int mixed_svd = 1;                         // tnml_set_svd_mode: float32 Jacobi + float64 refinement (kernels_narrow.hip phase 7a)
   double chol_thr = kCholThrDefault;         // off(G) / trace(G) above which the pivoted-Cholesky step runs (0 disables it)
   double trunc_thr = 0.999;                  // adaptive truncation threshold (tensor_svd's default argument)
   double prof_ms[4] = {0, 0, 0, 0};
@@ -237,8 +238,8 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipMalloc(&c->dbg, c->dbg_elems * sizeof(double)));
   HIP_TRY(hipMalloc(&c->status, 2 * sizeof(int)));      // [0] status word, [1] kept rank of the last adaptive step
   HIP_TRY(hipMemsetAsync(c->status, 0, 2 * sizeof(int), c->stream));
-  HIP_TRY(hipMalloc(&c->counters, 8 * sizeof(unsigned long long)));     // [0..2] Jacobi statistics, [4..7] fused-launch timing diagnostics
-  HIP_TRY(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMalloc(&c->counters, kCounterSlots * sizeof(unsigned long long)));     // see kCounterSlots (tnml_internal.h)
+  HIP_TRY(hipMemsetAsync(c->counters, 0, kCounterSlots * sizeof(unsigned long long), c->stream));
   c->tables_bytes = (size_t)N * std::max(sizeof(ChainSite), sizeof(NormChainSite));
   HIP_TRY(hipMalloc(&c->tables, c->tables_bytes));
   int rc = alloc_batch_buffers(c, b_capacity);
@@ -961,7 +962,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     n.metrics = c->metrics + 2 * (size_t)step;
     n.dbg = (c->debug || mode == 1) ? c->dbg : nullptr;
     n.Bdirect = Bdirect_dev;
-    n.svd_stop2 = c->svd_stop2;
+    n.svd_stop2 = c->svd_stop2; n.mixed_svd = c->mixed_svd;
     n.chol_thr = c->chol_thr;
     n.stop_after_update = mode == 1;
     if (fused) {
@@ -1261,7 +1262,7 @@ extern "C" int tnml_l2_term(tnml_ctx *c, const float *B_canon, int left_dir, flo
   n.Bnew = c->Bscr2;
   n.dbg = c->dbg; n.status = c->status; n.counters = nullptr;
   n.Bdirect = c->Bscr; n.stop_after_update = 1;
-  n.svd_stop2 = c->svd_stop2;
+  n.svd_stop2 = c->svd_stop2; n.mixed_svd = c->mixed_svd;
   rc = run_narrow(c, n, npath);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -1304,7 +1305,7 @@ extern "C" int tnml_svd_split(tnml_ctx *c, const float *mat, int rows, int cols,
   n.out_ahead = svh_dev; n.oa_s_m = cols; n.oa_s_d = g; n.oa_s_g = 1;
   n.dbg = c->dbg; n.status = c->status; n.counters = c->counters;
   n.Bdirect = c->Bscr;
-  n.svd_stop2 = c->svd_stop2;
+  n.svd_stop2 = c->svd_stop2; n.mixed_svd = c->mixed_svd;
   n.chol_thr = c->chol_thr;
   { int rc = run_narrow(c, n, npath); if (rc) return rc; }
   HIP_TRY(hipGetLastError());
@@ -1482,15 +1483,39 @@ extern "C" int tnml_get_counters(tnml_ctx *c, double *out8) {
   return TNML_OK;
 }
 
-extern "C" int tnml_svd_stats(tnml_ctx *c, int reset, double *out4) {
-  double *out3 = out4;
-  if (!c || !out3) return fail(TNML_ERR_ARG, "NULL argument");
+static int read_counters(tnml_ctx *c, int reset, unsigned long long *h) {
   HIP_TRY(hipSetDevice(c->device));
-  unsigned long long h[4] = {0, 0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(h, c->counters, kCounterSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  out3[0] = (double)h[0]; out3[1] = (double)h[1]; out3[2] = (double)h[2]; out4[3] = (double)h[3];
-  if (reset) HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof h, c->stream));
+  if (reset) {        // the Jacobi statistics only: [4..7] belong to the in-kernel timing diagnostics
+    HIP_TRY(hipMemsetAsync(c->counters, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters + 8, 0, (kCounterSlots - 8) * sizeof(unsigned long long), c->stream));
+  }
+  return TNML_OK;
+}
+
+extern "C" int tnml_svd_stats(tnml_ctx *c, int reset, double *out3) {
+  if (!c || !out3) return fail(TNML_ERR_ARG, "NULL argument");
+  unsigned long long h[kCounterSlots];
+  int rc = read_counters(c, reset, h);
+  if (rc) return rc;
+  out3[0] = (double)h[0]; out3[1] = (double)h[1]; out3[2] = (double)h[2];
+  return TNML_OK;
+}
+
+extern "C" int tnml_svd_stats_ex(tnml_ctx *c, int reset, double *out, int capacity) {
+  if (!c || !out || capacity < 1) return fail(TNML_ERR_ARG, "NULL argument / empty buffer");
+  unsigned long long h[kCounterSlots];
+  int rc = read_counters(c, reset, h);
+  if (rc) return rc;
+  const int src[7] = {0, 1, 2, 3, 8, 9, 10};
+  for (int i = 0; i < capacity && i < 7; ++i) out[i] = (double)h[src[i]];
+  return TNML_OK;
+}
+
+extern "C" int tnml_set_svd_mode(tnml_ctx *c, int mixed) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  c->mixed_svd = mixed ? 1 : 0;
   return TNML_OK;
 }
 
