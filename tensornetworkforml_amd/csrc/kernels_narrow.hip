@@ -662,6 +662,8 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   double *Vfin = nullptr;                  // eigenvectors, [row][column position]
   bool mixed_done = false;
   int rounds32 = 0, refine_its = 0;
+  unsigned long long t_m0 = 0, t_m1 = 0, t_m2 = 0;             // diagnostics (p.stamps): cycles of the float32 stage / K, E / steps
+  float dg_t0 = 0.f, dg_rel0 = 0.f, dg_t = 0.f, dg_rel = 0.f;
   const bool try_mixed = p.mixed_svd && n >= kMixedMinN && !(p.trunc_thr > 0.0);
   if (try_mixed) {
     double *bA = G0, *bB = G1, *bC = V0, *bD = k.Z + 3 * ne * ne;
@@ -775,6 +777,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       ++rounds32;
     };
     lds_barrier();                                                // float(G) complete
+    if (p.stamps && tid == 0) t_m0 = __builtin_amdgcn_s_memtime();
     kept2f = kept_scale32(Fc);
     if (tid == 0) { k.sFlag[6] = 0; k.sFlag[7] = 0; }
     if (isParam) {                                                // rotations of the very first round
@@ -802,6 +805,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       }
     }
     lds_barrier();
+    if (p.stamps && tid == 0) t_m1 = __builtin_amdgcn_s_memtime();
     // level 1: H0 = G V32 -> bD,  E = V32^T V32 - I -> float32 in bB (the float32 matrices of stage (1) are dead)
     {
       float *E32 = reinterpret_cast<float *>(bB);
@@ -818,6 +822,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     lds_barrier();
     const double final2 = p.svd_stop2 * p.svd_stop2;
     bool failed = false;
+    if (p.stamps && tid == 0) t_m2 = __builtin_amdgcn_s_memtime();
     for (int it = 0;; ++it) {
       const bool first = it == 0;                                 // E is folded into the first step only
       const float *E32 = reinterpret_cast<const float *>(bB);
@@ -868,6 +873,8 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       }
       lds_barrier();
       const unsigned urel = __builtin_amdgcn_readfirstlane(k.sFlag[0]), ut = __builtin_amdgcn_readfirstlane(k.sFlag[1]);
+      dg_t = __uint_as_float(ut); dg_rel = __uint_as_float(urel);
+      if (first) { dg_t0 = dg_t; dg_rel0 = dg_rel; }
       if (!first && urel == 0u) break;                            // every kept pair meets the criterion
       if (__uint_as_float(ut) > kMixedMaxT || it >= kMixedMaxIt) { failed = true; break; }
       // Z = I + Y + Y^2 / 2 -> bD
@@ -886,6 +893,12 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       lds_barrier();
       double *tsw = bB; bB = bC; bC = tsw;
       ++refine_its;
+    }
+    if (p.stamps && tid == 0) {
+      const unsigned long long t_m3 = __builtin_amdgcn_s_memtime();
+      p.stamps[34] = (double)rounds32; p.stamps[35] = (double)dg_t0; p.stamps[36] = (double)dg_rel0; p.stamps[37] = (double)refine_its;
+      p.stamps[38] = failed ? 1.0 : 0.0; p.stamps[39] = (double)(t_m1 - t_m0); p.stamps[40] = (double)(t_m2 - t_m1);
+      p.stamps[41] = (double)(t_m3 - t_m2); p.stamps[42] = (double)dg_t; p.stamps[43] = (double)dg_rel; p.stamps[44] = (double)kept2f;
     }
     if (!failed) {
       mixed_done = true;

@@ -1304,11 +1304,13 @@ extern "C" int tnml_svd_split(tnml_ctx *c, const float *mat, int rows, int cols,
   n.out_behind = us_dev; n.ob_s_h = D * m; n.ob_s_d = m; n.ob_s_m = 1;
   n.out_ahead = svh_dev; n.oa_s_m = cols; n.oa_s_d = g; n.oa_s_g = 1;
   n.dbg = c->dbg; n.status = c->status; n.counters = c->counters;
+  n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + kDbgSigma + 5 : nullptr;
   n.Bdirect = c->Bscr;
   n.svd_stop2 = c->svd_stop2; n.mixed_svd = c->mixed_svd;
   n.chol_thr = c->chol_thr;
   { int rc = run_narrow(c, n, npath); if (rc) return rc; }
   HIP_TRY(hipGetLastError());
+  c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = 0;
   HIP_TRY(hipMemcpyAsync(US, us_dev, (size_t)rows * m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(SVh, svh_dev, (size_t)m * cols * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -42,18 +42,99 @@ def shard_batch(X, y, rank, world):
 
 class FileGroup:
     """Host-side rendezvous of the ranks of ONE node without torch: a directory under /tmp keyed by the launcher's
-    MASTER_PORT and the launcher's PID (torch.distributed.run is the parent of every rank, so the key is common to the
-    job and unique to it).  Ranks exchange small values as files written atomically (write + rename) and poll for
-    each other's; every collective carries a sequence number, so nothing is ever read twice.  Used for the 128-byte
-    RCCL unique id, for barriers around timed regions and for max-over-ranks of a timing: never on the data path."""
+    MASTER_PORT, its run id and its PID (torch.distributed.run is the parent of every rank).  Ranks exchange small values as
+    files written atomically (write + rename) and poll for each other's.  Used for the 128-byte RCCL unique id, for barriers
+    around timed regions and for max-over-ranks of a timing: never on the data path.
+
+    The key alone is not trusted (a crashed earlier job, PID reuse, the same parent spawning ranks twice): the group opens
+    with a handshake that gives it a GENERATION.  Every rank draws a nonce and keeps publishing `hello_<rank>` (nonce, host
+    name); rank 0 first wipes and recreates the directory (mode 0700, owned by this user), collects one hello per rank and
+    publishes `gen` = its own nonce plus the nonces it saw; a rank accepts a `gen` file only if it lists the rank's own
+    nonce, so files of any other job -- older or concurrent -- are never read: every later file name carries the generation
+    and a sequence number.  Ranks on different hosts cannot meet in /tmp; the handshake then times out with that hint, and
+    ranks that do meet but report different host names (a shared /tmp) are refused."""
 
     def __init__(self, rank, world, key=None, root='/tmp', timeout=300.0):
+        import json, secrets, socket, time
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         if key is None:
-            key = '%s_%d' % (os.environ.get('MASTER_PORT', '29500'), os.getppid())
-        self.dir = os.path.join(root, 'tnml_rdzv_%s' % key)
-        os.makedirs(self.dir, exist_ok=True)
+            key = '%s_%s_%d' % (os.environ.get('MASTER_PORT', '29500'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())
+        key = ''.join(ch if (ch.isalnum() or ch in '_-.') else '_' for ch in str(key))
+        self.dir = os.path.join(root, 'tnml_rdzv_%s_u%d' % (key, os.getuid()))
         self.seq = 0
+        self.gen = None
+        nonce = secrets.token_hex(8)
+        host = socket.gethostname()
+        t_end = time.monotonic() + self.timeout
+        if self.rank == 0:
+            self._fresh_dir()
+            seen = {0: (nonce, host)}
+            while len(seen) < self.world:
+                for r in range(1, self.world):
+                    if r not in seen:
+                        v = self._try_read('hello_%d' % r)
+                        if v:
+                            try:
+                                d = json.loads(v.decode())
+                                seen[r] = (d['nonce'], d['host'])
+                            except (ValueError, KeyError):
+                                pass
+                if time.monotonic() > t_end:
+                    raise TimeoutError('rendezvous: rank 0 saw %d of %d ranks in %s (one process per GPU on ONE node is '
+                                       'required: ranks on other hosts cannot meet in /tmp)' % (len(seen), self.world, self.dir))
+                time.sleep(0.001)
+            hosts = sorted({h for _, h in seen.values()})
+            err = '' if len(hosts) == 1 else 'ranks on different hosts share %s: %s' % (self.dir, hosts)
+            self.gen = nonce
+            self._put('gen', json.dumps({'gen': nonce, 'nonces': {str(r): n for r, (n, _) in seen.items()}, 'error': err}).encode())
+            if err:
+                raise RuntimeError('rendezvous: ' + err)
+        else:
+            last = 0.0
+            while self.gen is None:
+                now = time.monotonic()
+                if now - last > 0.05:            # rank 0 may wipe the directory after this rank's first hello: keep saying it
+                    try:
+                        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+                        self._put('hello_%d' % self.rank, json.dumps({'nonce': nonce, 'host': host}).encode())
+                    except OSError:
+                        pass                      # the directory is being wiped under us: try again
+                    last = now
+                v = self._try_read('gen')
+                if v:
+                    try:
+                        d = json.loads(v.decode())
+                        if d['nonces'].get(str(self.rank)) == nonce:      # this job's generation, not a stale one
+                            if d.get('error'):
+                                raise RuntimeError('rendezvous: ' + d['error'])
+                            self.gen = d['gen']
+                    except (ValueError, KeyError):
+                        pass
+                if self.gen is None:
+                    if now > t_end:
+                        raise TimeoutError('rendezvous: rank %d never saw its generation in %s (rank 0 dead, or on another host?)'
+                                           % (self.rank, self.dir))
+                    time.sleep(0.001)
+
+    def _fresh_dir(self):
+        import shutil, stat
+        if os.path.lexists(self.dir):
+            st = os.lstat(self.dir)
+            if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid():
+                raise RuntimeError('rendezvous: %s exists and is not a directory of this user' % self.dir)
+            shutil.rmtree(self.dir, ignore_errors=True)
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+        st = os.lstat(self.dir)
+        if st.st_uid != os.getuid():
+            raise RuntimeError('rendezvous: %s is not owned by this user' % self.dir)
+        os.chmod(self.dir, 0o700)
+
+    def _try_read(self, name):
+        try:
+            with open(os.path.join(self.dir, name), 'rb') as fh:
+                return fh.read()
+        except OSError:
+            return None
 
     def _put(self, name, payload):
         tmp = os.path.join(self.dir, '.%s.%d.tmp' % (name, self.rank))
@@ -63,19 +144,19 @@ class FileGroup:
 
     def _get(self, name):
         import time
-        path = os.path.join(self.dir, name)
         t_end = time.monotonic() + self.timeout
-        while not os.path.exists(path):
+        while True:
+            v = self._try_read(name)
+            if v is not None:
+                return v
             if time.monotonic() > t_end:
-                raise TimeoutError('rank %d: %s never appeared (a peer died?)' % (self.rank, path))
+                raise TimeoutError('rank %d: %s never appeared in %s (a peer died?)' % (self.rank, name, self.dir))
             time.sleep(0.0002)
-        with open(path, 'rb') as fh:
-            return fh.read()
 
     def all_gather_bytes(self, payload):
         self.seq += 1
-        self._put('s%d_r%d' % (self.seq, self.rank), payload)
-        return [self._get('s%d_r%d' % (self.seq, r)) for r in range(self.world)]
+        self._put('%s_s%d_r%d' % (self.gen, self.seq, self.rank), payload)
+        return [self._get('%s_s%d_r%d' % (self.gen, self.seq, r)) for r in range(self.world)]
 
     def barrier(self):
         self.all_gather_bytes(b'1')
@@ -89,23 +170,27 @@ class FileGroup:
 
     def destroy_process_group(self):
         import shutil
+        global _group
         self.barrier()
         # rank 0 removes the directory only after every rank has left the barrier (said so with a file it never reads back)
-        self._put('bye_r%d' % self.rank, b'1')
+        self._put('%s_bye_r%d' % (self.gen, self.rank), b'1')
         if self.rank == 0:
             for r in range(self.world):
-                self._get('bye_r%d' % r)
+                self._get('%s_bye_r%d' % (self.gen, r))
             shutil.rmtree(self.dir, ignore_errors=True)
+        if _group is self:
+            _group = None                 # a later init_process_group opens a new generation
 
 
 _group = None
 
 
-def init_process_group(rank, world, key=None):
-    """Rendezvous of the ranks of this node (no torch.distributed: a file store, see FileGroup)."""
+def init_process_group(rank, world, *, key=None, timeout=300.0):
+    """Rendezvous of the ranks of this node (no torch.distributed: a file store, see FileGroup).  `key` is keyword-only: the
+    third positional argument of torch.distributed.init_process_group is a backend name, which must not become a directory."""
     global _group
     if _group is None or _group.world != world or _group.rank != rank:
-        _group = FileGroup(rank, world, key)
+        _group = FileGroup(rank, world, key, timeout=timeout)
     return _group
 
 

@@ -88,6 +88,11 @@ def _worker(rank, world, port, out_dir):
     dist.barrier()
     open(os.path.join(out_dir, 'ok%d' % rank), 'w').write('ok')
     grp.destroy_process_group()
+    # a second group of the same processes (same key): a new generation, nothing of the first one is read again
+    grp2 = tdist.init_process_group(rank, world)
+    assert grp2 is not grp and grp2.gen != grp.gen
+    assert grp2.broadcast_bytes(b'again' if rank == 0 else b'') == b'again'
+    grp2.destroy_process_group()
     dist.destroy_process_group()
 
 
@@ -138,5 +143,33 @@ def test_shard_bounds_cover_the_batch():
 
 def test_two_rank_sharded_step(tmp_path):
     world, port = 2, _free_port()
+    # leftovers of a crashed earlier job under the very key this job will use (same port, same parent pid): a stale
+    # generation file, a stale hello and a stale unique id must not be read by anybody
+    stale = '/tmp/tnml_rdzv_%d_none_%d_u%d' % (port, os.getpid(), os.getuid())
+    os.makedirs(stale, mode=0o700, exist_ok=True)
+    for name, payload in (('gen', b'{"gen": "dead", "nonces": {"0": "x", "1": "y"}, "error": ""}'), ('hello_1', b'{"nonce": "y", "host": "elsewhere"}'),
+                          ('dead_s1_r0', bytes(128)), ('s1_r0', bytes(128))):
+        with open(os.path.join(stale, name), 'wb') as fh:
+            fh.write(payload)
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ('ok%d' % r)) for r in range(world))
+    assert not os.path.exists(stale)          # the last group removed its directory
+
+
+def test_rendezvous_refuses_foreign_directory(tmp_path):
+    from tensornetworkforml_amd import dist as tdist
+    # a FILE where the directory should be: rank 0 must not follow or delete it
+    key = 'refuse_%d' % os.getpid()
+    path = '/tmp/tnml_rdzv_%s_u%d' % (key, os.getuid())
+    with open(path, 'w') as fh:
+        fh.write('not a directory')
+    try:
+        with pytest.raises(RuntimeError):
+            tdist.FileGroup(0, 1, key)
+    finally:
+        os.remove(path)
+    # world size 1 needs no peer: the handshake completes alone and the directory goes away again
+    g = tdist.FileGroup(0, 1, 'solo_%d' % os.getpid())
+    assert g.broadcast_bytes(b'x') == b'x'
+    g.destroy_process_group()
+    assert not os.path.exists(g.dir)
