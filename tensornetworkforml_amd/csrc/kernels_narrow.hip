@@ -667,6 +667,11 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   const bool try_mixed = p.mixed_svd && n >= kMixedMinN && !(p.trunc_thr > 0.0);
   if (try_mixed) {
     double *bA = G0, *bB = G1, *bC = V0, *bD = k.Z + 3 * ne * ne;
+    // fifth buffer: the copy of B_new the Gram phase read (fBp when the rows are the short side, else fB; the factor products of
+    // phase 9 read the other one) -- if it holds ne x ne doubles.  A fallback to the float64 iteration rebuilds it first.
+    float *Wdead = short_rows ? k.fBp : k.fB;
+    double *bX = ((size_t)Bs >= (size_t)2 * ne * ne && ((size_t)Wdead & 15) == 0) ? reinterpret_cast<double *>(Wdead) : nullptr;
+    const bool spare_used = bX != nullptr;
     float *F0 = reinterpret_cast<float *>(bB), *F1 = F0 + ne * ne;
     for (int i = wave_u; i < ne; i += NT >> 6)
       for (int j = tid & 63; j < ne; j += 64) F0[i * ne + j] = (float)G0[i * ne + j];
@@ -680,7 +685,10 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     float *Fc = F0, *Fn = F1;
     int cur32 = 0, last_big32 = 0;
     float kept2f = 0.f;
-    const float big32 = fminf(fmaxf((float)p.svd_stop2, 1e-7f), 1e-3f), abs2f = 1e-30f;
+    // "big" rotation of the float32 stage: the simultaneous float64 step needs every remaining 2x2 tangent below kMixedMaxT, and
+    // the merged tensors of a trained chain have a FLAT kept spectrum (singular values within ~1e-3 of each other, C3): the
+    // float32 iteration therefore runs until |g| / sqrt(a b) < ~1e-5, where t = g / gap is small even inside such a cluster
+    const float big32 = fminf(fmaxf((float)p.svd_stop2 * kMixedBigScale, 1e-12f), 1e-6f), abs2f = 1e-30f;
     auto kept_scale32 = [&](const float *F) -> float {            // as kept_scale below, on the float32 matrix; ends with a barrier
       const int i = tid & 63;
       const float li = i < n ? F[i * ne + i] : 0.f;
@@ -697,29 +705,22 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       *o = make_float4(r.c0, r.t * r.c0, r.t, 0.f);
       if (r.level >= 2) k.sFlag[6 + (applied & 1)] = applied + 1;
     };
-    auto round32 = [&]() {
+    const bool trAB = pA > pB;
+    auto round32 = [&](const bool xP = true, const bool xG = true, const bool xV = true) {
       const float4 *csc = cs32 + cur32 * np;
       const int big_slot = k.sFlag[6 + (rounds32 & 1)];           // consumed after this round's barrier
-      if (isParam) {
+      if (isParam && xP) {
         // look-ahead: pair `tid` of the NEXT round is (a, b) in today's positions; its three elements after today's rotations
         const float4 cA = csc[pA], cB = csc[pB];
         const float2 dA = *reinterpret_cast<const float2 *>(Fc + oAd);
         const float bAe = Fc[oAb];
         const float2 dB = *reinterpret_cast<const float2 *>(Fc + oBd);
         const float bBe = Fc[oBb];
-        float2 r0, r1;                                            // rows of block (A, B)
-        if (pA < pB) {
-          r0 = *reinterpret_cast<const float2 *>(Fc + oR0);
-          r1 = *reinterpret_cast<const float2 *>(Fc + oR1);
-        } else if (pA > pB) {                                     // stored as (B, A): transpose
-          const float2 s0 = *reinterpret_cast<const float2 *>(Fc + oR0);
-          const float2 s1 = *reinterpret_cast<const float2 *>(Fc + oR1);
-          r0 = make_float2(s0.x, s1.x);
-          r1 = make_float2(s0.y, s1.y);
-        } else {                                                  // n == 2: the pair meets itself again
-          r0 = dA;
-          r1 = make_float2(dA.y, bAe);
-        }
+        // block (A, B) is stored at (min, max): two 8-byte loads whatever the order, the transposition is a per-lane select
+        // (np > 1 on this path, so A != B)
+        const float2 s0 = *reinterpret_cast<const float2 *>(Fc + oR0);
+        const float2 s1 = *reinterpret_cast<const float2 *>(Fc + oR1);
+        const float2 r0 = make_float2(s0.x, trAB ? s1.x : s0.y), r1 = make_float2(trAB ? s0.y : s1.x, s1.y);
         const float na = ra ? fmaf(cA.z, dA.y, bAe) : fmaf(-cA.z, dA.y, dA.x);
         const float nb = rb ? fmaf(cB.z, dB.y, bBe) : fmaf(-cB.z, dB.y, dB.x);
         const float h0 = ra ? fmaf(cA.y, r0.x, cA.x * r1.x) : fmaf(cA.x, r0.x, -cA.y * r1.x);
@@ -727,7 +728,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
         const float ng = rb ? fmaf(cB.y, h0, cB.x * h1) : fmaf(cB.x, h0, -cB.y * h1);
         publish32(cs32 + (cur32 ^ 1) * np + tid, jacobi_rot_f32(na, nb, ng, kept2f, abs2f, big32), rounds32 + 1);
       }
-      if (isVwave) {                                              // whole waves: every lane runs the shifts
+      if (isVwave && xV) {                                        // whole waves: every lane runs the shifts
         const float4 q4 = csc[vLaneOk ? vQ : 0];
 #pragma unroll
         for (int r = 0; r < kVR; ++r) {
@@ -750,7 +751,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       }
 #pragma unroll
       for (int u = 0; u < MAXI; ++u) {
-        if (!itValid[u]) continue;
+        if (!itValid[u] || !xG) continue;
         const float4 q4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(csc) + itCsQ[u]);   // column pair
         const float4 p4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(csc) + itCsP[u]);   // row pair
         const float *src = Fc + itSrc[u];
@@ -805,6 +806,20 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       }
     }
     lds_barrier();
+#ifdef TNML_ROUND32_TIMING
+    if (p.stamps) {      // cycles per float32 round with roles switched off (on the dead float32 buffers)
+      for (int variant = 0; variant < 5; ++variant) {
+        const bool xP = variant == 0 || variant == 1, xG = variant == 0 || variant == 2, xV = variant == 0 || variant == 3;
+        lds_barrier();
+        const unsigned long long e0 = __builtin_amdgcn_s_memtime();
+        for (int rnd = 0; rnd < ne - 1; ++rnd) round32(xP, xG, xV);
+        const unsigned long long e1 = __builtin_amdgcn_s_memtime();
+        if (tid == 0) p.stamps[45 + variant] = (double)(e1 - e0) / (double)(ne - 1);
+      }
+      if (vLaneOk) for (int r = 0; r < kVR; ++r) for (int q = 0; q < 4; ++q) F0[(vP0 + r) * 4 + q] += vf[r][q];   // keep the V registers alive
+      lds_barrier();
+    }
+#endif
     if (p.stamps && tid == 0) t_m1 = __builtin_amdgcn_s_memtime();
     // level 1: H0 = G V32 -> bD,  E = V32^T V32 - I -> float32 in bB (the float32 matrices of stage (1) are dead)
     {
@@ -841,23 +856,24 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
         }
       }
       lds_barrier();
-      const double lmk = kKeptFrac * fmax(k.dRed[60], 0.0), kept2d = lmk * lmk;
+      const float lmk = (float)(kKeptFrac * fmax(k.dRed[60], 0.0)), kept2s = fmaxf(lmk * lmk, 1e-36f), final2f = (float)final2;
       float mx_rel = 0.f, mx_t = 0.f;
       for (int i = wave_u; i < ne; i += NT >> 6)
         for (int j = tid & 63; j < ne; j += 64) {
           if (i < j) {
             const double di = k.dLam[i], dj = k.dLam[j];
             const float e = first ? E32[i * ne + j] : 0.f;
-            const double g = bA[i * ne + j] - 0.5 * (double)e * (di + dj);
+            // float64 only where cancellation matters (the corrected element, the gap); the criterion itself in float32 (G is
+            // scaled to trace ~1: a product that underflows is below any kept2)
+            const float gf = (float)fma(-0.5 * (double)e, di + dj, bA[i * ne + j]), df = (float)(dj - di);
             const bool kp = i < n && j < n && (k.sOrd[i] < m || k.sOrd[j] < m);
-            const double sc = fmax(fabs(di * dj), kept2d), g2 = g * g;
+            const float scf = fmaxf(fabsf((float)di * (float)dj), kept2s), g2f = gf * gf;
             float t = 0.f;
-            if (kp && g2 > fmax(final2 * sc, abs2)) {
-              const float df = (float)(dj - di), gf = (float)g;
-              const float hyp = __builtin_amdgcn_sqrtf(fmaf(df, df, 4.f * gf * gf));
+            if (kp && g2f > fmaxf(final2f * scf, 1e-37f)) {
+              const float hyp = __builtin_amdgcn_sqrtf(fmaf(df, df, 4.f * g2f));
               const float den = df + copysignf(hyp, df);
               t = den != 0.f ? 2.f * gf * __builtin_amdgcn_rcpf(den) : 0.f;
-              mx_rel = fmaxf(mx_rel, (float)(g2 / sc));
+              mx_rel = fmaxf(mx_rel, g2f * __builtin_amdgcn_rcpf(scf));
               mx_t = fmaxf(mx_t, fabsf(t));
             }
             Y32[i * ne + j] = t - 0.5f * e;
@@ -878,20 +894,29 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       if (!first && urel == 0u) break;                            // every kept pair meets the criterion
       if (__uint_as_float(ut) > kMixedMaxT || it >= kMixedMaxIt) { failed = true; break; }
       // Z = I + Y + Y^2 / 2 -> bD
-      mm_lds(1, ne, ne, ne, Y32, 0, ne, 1, Y32, 0, ne, 1,
-             [&](int, int i, int j, double v) { bD[i * ne + j] = 0.5 * v + (double)Y32[i * ne + j] + (i == j ? 1.0 : 0.0); });
+      // (float32 matrix pipe: Y is float32 data of size <= kMixedMaxT, so Y^2 / 2 is exact to ~1e-11)
+      mm_lds_f32(ne, ne, ne, Y32, ne, 1, Y32, ne, 1,
+                 [&](int i, int j, float v) { bD[i * ne + j] = 0.5 * (double)v + (double)Y32[i * ne + j] + (i == j ? 1.0 : 0.0); });
       lds_barrier();
       // H = K Z -> bB (E and Y are dead)
       mm_lds(1, ne, ne, ne, bA, 0, ne, 1, bD, 0, ne, 1, [&](int, int i, int j, double v) { bB[i * ne + j] = v; });
       lds_barrier();
-      // K' = Z^T H -> bA
-      mm_lds(1, ne, ne, ne, bD, 0, 1, ne, bB, 0, ne, 1,
-             [&](int, int i, int j, double v) { if (i <= j) { bA[i * ne + j] = v; bA[j * ne + i] = v; } }, true);
+      // K' = Z^T H -> bA and V' = V Z: independent.  With a fifth buffer (the copy of the matrix the Gram phase read is dead:
+      // bX) they share a level, V' landing in bX; otherwise V' follows into bB once H is dead.  The new basis buffer and the
+      // scratch buffer of the next step swap roles.
+      {
+        const int slot = mm_lds(1, ne, ne, ne, bD, 0, 1, ne, bB, 0, ne, 1,
+                                [&](int, int i, int j, double v) { if (i <= j) { bA[i * ne + j] = v; bA[j * ne + i] = v; } }, true);
+        if (bX) mm_lds(1, ne, ne, ne, bC, 0, ne, 1, bD, 0, ne, 1, [&](int, int i, int j, double v) { bX[i * ne + j] = v; }, false, slot);
+      }
       lds_barrier();
-      // V' = V Z -> bB, which becomes the basis; the old basis buffer is the scratch of the next step
-      mm_lds(1, ne, ne, ne, bC, 0, ne, 1, bD, 0, ne, 1, [&](int, int i, int j, double v) { bB[i * ne + j] = v; });
-      lds_barrier();
-      double *tsw = bB; bB = bC; bC = tsw;
+      if (bX) {
+        double *tsw = bX; bX = bC; bC = tsw;                     // basis <- V', the old basis buffer becomes the spare
+      } else {
+        mm_lds(1, ne, ne, ne, bC, 0, ne, 1, bD, 0, ne, 1, [&](int, int i, int j, double v) { bB[i * ne + j] = v; });
+        lds_barrier();
+        double *tsw = bB; bB = bC; bC = tsw;
+      }
       ++refine_its;
     }
     if (p.stamps && tid == 0) {
@@ -904,6 +929,13 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       mixed_done = true;
       Gfin = bA; Vfin = bC;
     } else {
+      if (spare_used) {                                           // the Gram operand was the spare buffer: rebuild it from the other copy
+        for (int row = wave_u; row < r; row += NT >> 6)
+          for (int x = tid & 63; x < c; x += 64) {
+            if (short_rows) k.fBp[row * (c + 1) + x] = k.fB[row * c + x]; else k.fB[row * c + x] = k.fBp[row * (c + 1) + x];
+          }
+        lds_barrier();
+      }
       gram_phase();                                               // the float64 iteration starts from G again
       scale_phase();
     }

@@ -26,6 +26,7 @@ constexpr int kMixedMinN = 16;
 constexpr int kMixedMaxSweeps = 10;
 constexpr int kMixedMaxIt = 3;
 constexpr float kMixedMaxT = 0.02f;
+constexpr float kMixedBigScale = 1e-4f;   // float32 stage: "big" rotation = g^2 / (a b) above svd_stop2 * this (1e-10 by default)
 constexpr int kCounterSlots = 16;   // device counters: [0..3] Jacobi statistics, [4..7] fused-launch timing diagnostics, [8..10] mixed path
 
 // A plain (label-free) core or the label core addressed in the sweep-relative frame.

@@ -95,7 +95,7 @@ def tangents(K, E, m, final2):
     return X, np.where(act, g * g / sc, 0).max()
 
 
-def svd_mixed(W, m, big32=1e-6, final2=1e-12):
+def svd_mixed(W, m, big32=1e-10, final2=1e-12):
     W = W.astype(np.float64); n = W.shape[0]
     G = W @ W.T; sc = 2.0 ** np.frexp(np.trace(G))[1]; G = G / sc
     r32, _, V = jacobi_rounds(G, m, f32, big32)
