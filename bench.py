@@ -147,7 +147,6 @@ def main():
     ap.add_argument('--ref-form-budget', type=float, default=25.0, help='seconds for cpu_baseline_reference_form (0 = skip)')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--svd-stop', type=float, default=None, help='Jacobi stopping threshold (tnml_set_svd_stop); default: the library default')
-    ap.add_argument('--svd-f64', action='store_true', help='all-float64 Jacobi iteration instead of the mixed-precision decomposition (tnml_set_svd_mode(ctx, 0))')
     ap.add_argument('--no-cold', action='store_true', help='skip the re-initialised (cold start) passes')
     ap.add_argument('--no-resident', action='store_true', help='skip the secondary single-resident-batch measurement')
     ap.add_argument('--classic', action='store_true', help='classic launch sequence instead of the pipelined single-launch step')
@@ -174,8 +173,6 @@ def main():
     ctx = _hip.Context(N, D, L, M, b, device=local_rank)
     if args.svd_stop is not None:
         ctx.set_svd_stop(args.svd_stop)
-    if args.svd_f64:
-        ctx.set_svd_mode(False)
     tdist.attach_comm(ctx, rank, world)
     if args.sync_interval:
         ctx.set_sync_interval(args.sync_interval)
@@ -249,9 +246,7 @@ def main():
         chol = ctx.cholesky_steps
         return dict(dt=dt, sweep_ms=sweep_ms, launches=n_launch, pipe_steps=n_steps_pipe, counters=cnt,
                     sweeps_per_svd=sw_tot / max(n_svd, 1), rounds_per_svd=rounds_tot / max(n_svd, 1),
-                    cholesky_fraction=chol / max(n_svd, 1),
-                    mixed=dict(fraction_of_svds=ctx.mixed_svds / max(n_svd, 1), float64_steps_per_svd=ctx.mixed_steps / max(ctx.mixed_svds, 1),
-                               fallback_fraction=ctx.mixed_fallbacks / max(ctx.mixed_svds, 1)))
+                    cholesky_fraction=chol / max(n_svd, 1))
 
     ctx.profile_reset()
     ctx.profile_enable(2)
@@ -320,7 +315,7 @@ def main():
         'counters': main_run['counters'],
         # the SVD is iterative: how much work the timed passes actually contained
         'jacobi': {'sweeps_per_svd': main_run['sweeps_per_svd'], 'rounds_per_svd': main_run['rounds_per_svd'],
-                   'cholesky_fraction': main_run['cholesky_fraction'], 'mixed_precision': main_run['mixed'],
+                   'cholesky_fraction': main_run['cholesky_fraction'],
                    'svd_stop2': args.svd_stop if args.svd_stop is not None else 1e-6},
     }
 
@@ -410,7 +405,7 @@ def main():
             one_pass(rotate=False)
         r = timed(args.steps, rotate=False)
         out['resident_batch'] = {'value': (1 if strong else world) * sweep_steps / r['dt'], 'unit': 'sweep-steps/s',
-                                 'jacobi_sweeps_per_svd': r['sweeps_per_svd'], 'cholesky_fraction': r['cholesky_fraction'], 'mixed_precision': r['mixed']}
+                                 'jacobi_sweeps_per_svd': r['sweeps_per_svd'], 'cholesky_fraction': r['cholesky_fraction']}
 
     if not args.no_cold:
         # "cold" passes: network re-initialised (random cores, calibrated) and swept twice -- the regime of the first
@@ -419,7 +414,7 @@ def main():
         init_network()
         r = timed(2)
         out['cold_start'] = {'value': (1 if strong else world) * 2 * (N - 1) / r['dt'], 'unit': 'sweep-steps/s', 'passes': 2,
-                             'jacobi_sweeps_per_svd': r['sweeps_per_svd'], 'cholesky_fraction': r['cholesky_fraction'], 'mixed_precision': r['mixed']}
+                             'jacobi_sweeps_per_svd': r['sweeps_per_svd'], 'cholesky_fraction': r['cholesky_fraction']}
 
     if rank == 0 and args.cpu_steps > 0:
         rate, t_fwd, t_step, st, fcpu, Xc, y1h = cpu_baseline(N, M, D, L, b, args.cpu_steps, 1234)

@@ -229,15 +229,9 @@ int tnml_profile_reset(tnml_ctx *ctx);
 int tnml_get_counters(tnml_ctx *ctx, double *out8);
 /* always-on counters of the SVD since the last reset: out3 = {Jacobi sweeps, number of SVDs, Jacobi rounds (one barrier each)} */
 int tnml_svd_stats(tnml_ctx *ctx, int reset, double *out3);
-/* the same with a capacity: out[0..capacity) of {sweeps, SVDs, rounds, SVDs that took the pivoted-Cholesky step,
- * SVDs that started on the mixed-precision path, simultaneous float64 steps those made, SVDs that fell back from it to the
- * float64 iteration}; entries beyond the seventh are left untouched */
+/* the same with a capacity: out[0..capacity) of {sweeps, SVDs, rounds, SVDs that took the pivoted-Cholesky step}; entries beyond
+ * the fourth are left untouched */
 int tnml_svd_stats_ex(tnml_ctx *ctx, int reset, double *out, int capacity);
-/* The decomposition of a merged tensor whose short side is >= 16 (fixed / reference truncation) runs its Jacobi iteration in
- * float32 and finishes in float64 on the matrix cores ("The SVD"): kept singular values and the truncated product
- * to float64 accuracy, discarded singular values (no reference analogue: tensor_svd drops them, Network_class.py:898-945) to
- * ~1e-4 sigma_max.  mixed = 0 restores the all-float64 Jacobi iteration of rounds 1-2. */
-int tnml_set_svd_mode(tnml_ctx *ctx, int mixed);
 
 /* Host-side planning helper, exported so that CPU tests can check the bond bookkeeping without a
  * GPU: truncation rank kept by tensor_svd (Network_class.py:894-945) for a step on sites

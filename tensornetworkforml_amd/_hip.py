@@ -28,7 +28,7 @@ SYMBOLS = [
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
     'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict', 'tnml_set_trunc_threshold',
     'tnml_set_sync_interval', 'tnml_set_step_pipeline', 'tnml_stage_batch', 'tnml_select_batch', 'tnml_get_counters',
-    'tnml_svd_stats_ex', 'tnml_set_svd_mode',
+    'tnml_svd_stats_ex',
 ]
 
 
@@ -85,7 +85,6 @@ def lib():
         L.tnml_profile_reset.argtypes = [vp]
         L.tnml_svd_stats.argtypes = [vp, C.c_int, f64p]
         L.tnml_svd_stats_ex.argtypes = [vp, C.c_int, f64p, C.c_int]
-        L.tnml_set_svd_mode.argtypes = [vp, C.c_int]
         L.tnml_trunc_rank.argtypes = [C.c_int] * 9
         L.tnml_update_B.argtypes = [vp, f32p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float,
                                     f64p, C.c_size_t, f32p]
@@ -378,16 +377,11 @@ class Context:
         _chk(lib().tnml_profile_reset(self._h))
 
     def svd_stats(self, reset=False):
-        """(total Jacobi sweeps, SVDs, total rounds) since the last reset.  Side effect: `cholesky_steps`, `mixed_svds`,
-        `mixed_steps` (simultaneous float64 steps of the mixed-precision path) and `mixed_fallbacks` hold the other counters."""
-        out = (C.c_double * 7)()
-        _chk(lib().tnml_svd_stats_ex(self._h, int(bool(reset)), out, 7))
-        self.cholesky_steps, self.mixed_svds, self.mixed_steps, self.mixed_fallbacks = out[3], out[4], out[5], out[6]
+        """(total Jacobi sweeps, SVDs, total rounds) since the last reset; `cholesky_steps` holds the fourth counter."""
+        out = (C.c_double * 4)()
+        _chk(lib().tnml_svd_stats_ex(self._h, int(bool(reset)), out, 4))
+        self.cholesky_steps = out[3]
         return out[0], out[1], out[2]
-
-    def set_svd_mode(self, mixed=True):
-        """True (default): float32 Jacobi + float64 refinement on the matrix cores; False: the all-float64 iteration."""
-        _chk(lib().tnml_set_svd_mode(self._h, int(bool(mixed))))
 
     def counters(self):
         """Work since the last profile_reset: dict of sweep steps, algorithmic bytes / flops, forwards, launches, device ms."""

@@ -639,308 +639,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   const int oR0 = pA <= pB ? (2 * pA) * ne + 2 * pB : (2 * pB) * ne + 2 * pA, oR1 = oR0 + ne;   // stored block (min, max)
 
   if (p.stamps && tid == 0) t_c1 = __builtin_amdgcn_s_memtime();
-  // ---- phase 7a: mixed-precision eigen-decomposition (round 3) -------------------------------------------------------
-  // A float64 Jacobi round is a chain of dependent float64 operations (40 cycles each on gfx950): ~1100 cycles, 70 rounds
-  // per decomposition once the chain has settled, 220 on a fresh network.  The same round in float32 is bound by the LDS
-  // round trip of its one barrier.  So:
-  //   (1) two-sided Jacobi on float(G), V32 in float32 registers, same tournament, same look-ahead parameter wave, same
-  //       sliding-window stop: V32 diagonalises G to float32 accuracy and is orthogonal to ~1e-5;
-  //   (2) float64, on the matrix cores: K = V32^T G V32 and E = V32^T V32 - I.  With Z orthonormalising the basis to first
-  //       order in E and rotating every pair that still violates the convergence criterion by its exact 2x2 Jacobi angle,
-  //       all pairs AT ONCE,      Z = I + Y + Y^2 / 2,   Y = X - E / 2,   X[p][q] = -X[q][p] = t_pq,
-  //       G' = Z^T K Z is similar to G up to O(E X, X^4) and its off-diagonals are the square of the old ones (every 2x2 angle
-  //       is tiny after (1): first-order perturbation theory, with the Jacobi formula instead of g / gap so that a close pair
-  //       is still rotated correctly); V = V32 Z.  The criterion is checked on G' and the step repeated if needed (1.0-1.5
-  //       steps on merged tensors of training runs, tests/emulation/jacobi_mixed_emulation.py).
-  // Pairs of two DISCARDED directions are left alone: float32 cannot resolve eigenvalues below ~1e-7 of the largest, their
-  // 2x2 angles are of order one, and nothing that is kept depends on them (kept singular values: relative error ~1e-10;
-  // discarded ones are Rayleigh quotients, good to ~1e-4 sigma_max).  A kept pair that needs a large angle (|t| > kMixedMaxT:
-  // two kept eigenvalues closer than float32 resolves) or a third repetition sends the decomposition down the float64
-  // iteration below (the Gram matrix is formed again).  Adaptive truncation, which reads the whole spectrum, and matrices
-  // below kMixedMinN always take the float64 iteration.
-  const double *Gfin = nullptr;            // diag = eigenvalues / 2^sc_exp
-  double *Vfin = nullptr;                  // eigenvectors, [row][column position]
-  bool mixed_done = false;
-  int rounds32 = 0, refine_its = 0;
-  unsigned long long t_m0 = 0, t_m1 = 0, t_m2 = 0;             // diagnostics (p.stamps): cycles of the float32 stage / K, E / steps
-  float dg_t0 = 0.f, dg_rel0 = 0.f, dg_t = 0.f, dg_rel = 0.f;
-  const bool try_mixed = p.mixed_svd && n >= kMixedMinN && !(p.trunc_thr > 0.0);
-  if (try_mixed) {
-    double *bA = G0, *bB = G1, *bC = V0, *bD = k.Z + 3 * ne * ne;
-    // fifth buffer: the copy of B_new the Gram phase read (fBp when the rows are the short side, else fB; the factor products of
-    // phase 9 read the other one) -- if it holds ne x ne doubles.  A fallback to the float64 iteration rebuilds it first.
-    float *Wdead = short_rows ? k.fBp : k.fB;
-    double *bX = ((size_t)Bs >= (size_t)2 * ne * ne && ((size_t)Wdead & 15) == 0) ? reinterpret_cast<double *>(Wdead) : nullptr;
-    const bool spare_used = bX != nullptr;
-    float *F0 = reinterpret_cast<float *>(bB), *F1 = F0 + ne * ne;
-    for (int i = wave_u; i < ne; i += NT >> 6)
-      for (int j = tid & 63; j < ne; j += 64) F0[i * ne + j] = (float)G0[i * ne + j];
-    float4 *cs32 = reinterpret_cast<float4 *>(k.dCS);            // [2][np]: (c, s, t, -) of every pair, two rounds in flight
-    float vf[kVR][4];
-#pragma unroll
-    for (int r = 0; r < kVR; ++r) {
-      const float one = (vP0 + r == vQ) ? 1.f : 0.f;
-      vf[r][0] = one; vf[r][1] = 0.f; vf[r][2] = 0.f; vf[r][3] = one;
-    }
-    float *Fc = F0, *Fn = F1;
-    int cur32 = 0, last_big32 = 0;
-    float kept2f = 0.f;
-    // "big" rotation of the float32 stage: the simultaneous float64 step needs every remaining 2x2 tangent below kMixedMaxT, and
-    // the merged tensors of a trained chain have a FLAT kept spectrum (singular values within ~1e-3 of each other, C3): the
-    // float32 iteration therefore runs until |g| / sqrt(a b) < ~1e-5, where t = g / gap is small even inside such a cluster
-    const float big32 = fminf(fmaxf((float)p.svd_stop2 * kMixedBigScale, 1e-12f), 1e-6f), abs2f = 1e-30f;
-    auto kept_scale32 = [&](const float *F) -> float {            // as kept_scale below, on the float32 matrix; ends with a barrier
-      const int i = tid & 63;
-      const float li = i < n ? F[i * ne + i] : 0.f;
-      for (int j = wave_u; j < n; j += NT >> 6) {
-        const float lj = F[j * ne + j];
-        const int rank = __popcll(__ballot(i < n && ((li > lj) || (li == lj && i < j))));
-        if (i == 0 && rank == m - 1) k.dRed[60] = (double)lj;
-      }
-      lds_barrier();
-      const float lm = (float)kKeptFrac * fmaxf((float)k.dRed[60], 0.f);
-      return fmaxf(lm * lm, 1e-36f);
-    };
-    auto publish32 = [&](float4 *o, const RotT &r, int applied) {
-      *o = make_float4(r.c0, r.t * r.c0, r.t, 0.f);
-      if (r.level >= 2) k.sFlag[6 + (applied & 1)] = applied + 1;
-    };
-    const bool trAB = pA > pB;
-    auto round32 = [&](const bool xP = true, const bool xG = true, const bool xV = true) {
-      const float4 *csc = cs32 + cur32 * np;
-      const int big_slot = k.sFlag[6 + (rounds32 & 1)];           // consumed after this round's barrier
-      if (isParam && xP) {
-        // look-ahead: pair `tid` of the NEXT round is (a, b) in today's positions; its three elements after today's rotations
-        const float4 cA = csc[pA], cB = csc[pB];
-        const float2 dA = *reinterpret_cast<const float2 *>(Fc + oAd);
-        const float bAe = Fc[oAb];
-        const float2 dB = *reinterpret_cast<const float2 *>(Fc + oBd);
-        const float bBe = Fc[oBb];
-        // block (A, B) is stored at (min, max): two 8-byte loads whatever the order, the transposition is a per-lane select
-        // (np > 1 on this path, so A != B)
-        const float2 s0 = *reinterpret_cast<const float2 *>(Fc + oR0);
-        const float2 s1 = *reinterpret_cast<const float2 *>(Fc + oR1);
-        const float2 r0 = make_float2(s0.x, trAB ? s1.x : s0.y), r1 = make_float2(trAB ? s0.y : s1.x, s1.y);
-        const float na = ra ? fmaf(cA.z, dA.y, bAe) : fmaf(-cA.z, dA.y, dA.x);
-        const float nb = rb ? fmaf(cB.z, dB.y, bBe) : fmaf(-cB.z, dB.y, dB.x);
-        const float h0 = ra ? fmaf(cA.y, r0.x, cA.x * r1.x) : fmaf(cA.x, r0.x, -cA.y * r1.x);
-        const float h1 = ra ? fmaf(cA.y, r0.y, cA.x * r1.y) : fmaf(cA.x, r0.y, -cA.y * r1.y);
-        const float ng = rb ? fmaf(cB.y, h0, cB.x * h1) : fmaf(cB.x, h0, -cB.y * h1);
-        publish32(cs32 + (cur32 ^ 1) * np + tid, jacobi_rot_f32(na, nb, ng, kept2f, abs2f, big32), rounds32 + 1);
-      }
-      if (isVwave && xV) {                                        // whole waves: every lane runs the shifts
-        const float4 q4 = csc[vLaneOk ? vQ : 0];
-#pragma unroll
-        for (int r = 0; r < kVR; ++r) {
-          if (r >= vr) break;                                     // wave-uniform
-          // columns by R_Q: (v1, v2) -> (c v1 - s v2, s v1 + c v2)
-          const float n11 = fmaf(q4.x, vf[r][0], -q4.y * vf[r][1]), n12 = fmaf(q4.y, vf[r][0], q4.x * vf[r][1]);
-          const float n21 = fmaf(q4.x, vf[r][2], -q4.y * vf[r][3]), n22 = fmaf(q4.y, vf[r][2], q4.x * vf[r][3]);
-          if (np > 1) {
-            const float t1 = dpp_f32<0x138>(n11), t2 = dpp_f32<0x138>(n21);      // top column of pair Q-1
-            const float b1 = dpp_f32<0x138>(n12), b2 = dpp_f32<0x138>(n22);      // bottom column of pair Q-1
-            const float c1 = dpp_f32<0x130>(n12), c2 = dpp_f32<0x130>(n22);      // bottom column of pair Q+1
-            vf[r][0] = vQ == 0 ? n11 : (vQ == 1 ? b1 : t1);
-            vf[r][2] = vQ == 0 ? n21 : (vQ == 1 ? b2 : t2);
-            vf[r][1] = vQ == np - 1 ? n11 : c1;
-            vf[r][3] = vQ == np - 1 ? n21 : c2;
-          } else {
-            vf[r][0] = n11; vf[r][1] = n12; vf[r][2] = n21; vf[r][3] = n22;
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < MAXI; ++u) {
-        if (!itValid[u] || !xG) continue;
-        const float4 q4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(csc) + itCsQ[u]);   // column pair
-        const float4 p4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(csc) + itCsP[u]);   // row pair
-        const float *src = Fc + itSrc[u];
-        const float2 r0 = *reinterpret_cast<const float2 *>(src);
-        float2 r1 = *reinterpret_cast<const float2 *>(src + ne);
-        if (itDiag[u]) r1.x = r0.y;                               // lower element of a diagonal block = its mirror
-        // R_P^T . blk . R_Q,  R = [[c, s], [-s, c]]
-        const float a11 = fmaf(p4.x, r0.x, -p4.y * r1.x), a12 = fmaf(p4.x, r0.y, -p4.y * r1.y);
-        const float a21 = fmaf(p4.y, r0.x, p4.x * r1.x), a22 = fmaf(p4.y, r0.y, p4.x * r1.y);
-        float n11 = fmaf(q4.x, a11, -q4.y * a12), n12 = fmaf(q4.y, a11, q4.x * a12);
-        float n21 = fmaf(q4.x, a21, -q4.y * a22), n22 = fmaf(q4.y, a21, q4.x * a22);
-        if (itDiag[u] && q4.z != 0.f) {                           // the annihilated element exactly, the diagonal in its stable form
-          n12 = 0.f; n21 = 0.f;
-          n11 = fmaf(-q4.z, r0.y, r0.x); n22 = fmaf(q4.z, r0.y, r1.y);
-        }
-        Fn[itD11[u]] = n11; Fn[itD12[u]] = n12;
-        if (!itDiag[u]) Fn[itD21[u]] = n21;
-        Fn[itD22[u]] = n22;
-      }
-      lds_barrier();
-      float *tsw = Fc; Fc = Fn; Fn = tsw;
-      cur32 ^= 1;
-      last_big32 = max(last_big32, big_slot);
-      ++rounds32;
-    };
-    lds_barrier();                                                // float(G) complete
-    if (p.stamps && tid == 0) t_m0 = __builtin_amdgcn_s_memtime();
-    kept2f = kept_scale32(Fc);
-    if (tid == 0) { k.sFlag[6] = 0; k.sFlag[7] = 0; }
-    if (isParam) {                                                // rotations of the very first round
-      const float2 top = *reinterpret_cast<const float2 *>(Fc + (2 * tid) * ne + 2 * tid);
-      publish32(cs32 + cur32 * np + tid, jacobi_rot_f32(top.x, Fc[(2 * tid + 1) * ne + 2 * tid + 1], top.y, kept2f, abs2f, big32), 0);
-    }
-    lds_barrier();
-    bool conv32 = false;
-    for (int sw32 = 0; sw32 < kMixedMaxSweeps && !conv32; ++sw32) {
-      for (int rnd = 0; rnd < ne - 1; ++rnd) {
-        round32();
-        if (rounds32 - __builtin_amdgcn_readfirstlane(last_big32) >= ne - 1) { conv32 = true; break; }
-      }
-      if (!conv32) kept2f = kept_scale32(Fc);
-    }
-    // V32 leaves the registers as float64 numbers: [row][column position]
-    if (vLaneOk) {
-#pragma unroll
-      for (int r = 0; r < kVR; ++r) {
-        const int P = vP0 + r;
-        if (r < vr && P < np) {
-          *reinterpret_cast<double2 *>(bC + (2 * P) * ne + 2 * vQ) = make_double2((double)vf[r][0], (double)vf[r][1]);
-          *reinterpret_cast<double2 *>(bC + (2 * P + 1) * ne + 2 * vQ) = make_double2((double)vf[r][2], (double)vf[r][3]);
-        }
-      }
-    }
-    lds_barrier();
-#ifdef TNML_ROUND32_TIMING
-    if (p.stamps) {      // cycles per float32 round with roles switched off (on the dead float32 buffers)
-      for (int variant = 0; variant < 5; ++variant) {
-        const bool xP = variant == 0 || variant == 1, xG = variant == 0 || variant == 2, xV = variant == 0 || variant == 3;
-        lds_barrier();
-        const unsigned long long e0 = __builtin_amdgcn_s_memtime();
-        for (int rnd = 0; rnd < ne - 1; ++rnd) round32(xP, xG, xV);
-        const unsigned long long e1 = __builtin_amdgcn_s_memtime();
-        if (tid == 0) p.stamps[45 + variant] = (double)(e1 - e0) / (double)(ne - 1);
-      }
-      if (vLaneOk) for (int r = 0; r < kVR; ++r) for (int q = 0; q < 4; ++q) F0[(vP0 + r) * 4 + q] += vf[r][q];   // keep the V registers alive
-      lds_barrier();
-    }
-#endif
-    if (p.stamps && tid == 0) t_m1 = __builtin_amdgcn_s_memtime();
-    // level 1: H0 = G V32 -> bD,  E = V32^T V32 - I -> float32 in bB (the float32 matrices of stage (1) are dead)
-    {
-      float *E32 = reinterpret_cast<float *>(bB);
-      const int slot = mm_lds(1, ne, ne, ne, bA, 0, ne, 1, bC, 0, ne, 1, [&](int, int i, int j, double v) { bD[i * ne + j] = v; });
-      mm_lds(1, ne, ne, ne, bC, 0, 1, ne, bC, 0, ne, 1,
-             [&](int, int i, int j, double v) {
-               if (i <= j) { const float e = (float)(v - (i == j ? 1.0 : 0.0)); E32[i * ne + j] = e; E32[j * ne + i] = e; }
-             }, true, slot);
-    }
-    lds_barrier();
-    // level 2: K = V32^T H0 -> bA (G is dead), both triangles from the upper one
-    mm_lds(1, ne, ne, ne, bC, 0, 1, ne, bD, 0, ne, 1,
-           [&](int, int i, int j, double v) { if (i <= j) { bA[i * ne + j] = v; bA[j * ne + i] = v; } }, true);
-    lds_barrier();
-    const double final2 = p.svd_stop2 * p.svd_stop2;
-    bool failed = false;
-    if (p.stamps && tid == 0) t_m2 = __builtin_amdgcn_s_memtime();
-    for (int it = 0;; ++it) {
-      const bool first = it == 0;                                 // E is folded into the first step only
-      const float *E32 = reinterpret_cast<const float *>(bB);
-      float *Y32 = reinterpret_cast<float *>(bB) + ne * ne;
-      // diagonal in the orthonormalised basis, ranks, kept set
-      for (int i = tid; i < ne; i += NT) k.dLam[i] = bA[i * ne + i] * (1.0 - (first ? (double)E32[i * ne + i] : 0.0));
-      if (tid == 0) { k.sFlag[0] = 0; k.sFlag[1] = 0; }
-      lds_barrier();
-      {
-        const int i = tid & 63;
-        const double li = i < n ? k.dLam[i] : 0.0;
-        for (int j = wave_u; j < n; j += NT >> 6) {
-          const double lj = k.dLam[j];
-          const int rank = __popcll(__ballot(i < n && ((li > lj) || (li == lj && i < j))));
-          if (i == 0) { k.sOrd[j] = rank; if (rank == m - 1) k.dRed[60] = lj; }
-        }
-      }
-      lds_barrier();
-      const float lmk = (float)(kKeptFrac * fmax(k.dRed[60], 0.0)), kept2s = fmaxf(lmk * lmk, 1e-36f), final2f = (float)final2;
-      float mx_rel = 0.f, mx_t = 0.f;
-      for (int i = wave_u; i < ne; i += NT >> 6)
-        for (int j = tid & 63; j < ne; j += 64) {
-          if (i < j) {
-            const double di = k.dLam[i], dj = k.dLam[j];
-            const float e = first ? E32[i * ne + j] : 0.f;
-            // float64 only where cancellation matters (the corrected element, the gap); the criterion itself in float32 (G is
-            // scaled to trace ~1: a product that underflows is below any kept2)
-            const float gf = (float)fma(-0.5 * (double)e, di + dj, bA[i * ne + j]), df = (float)(dj - di);
-            const bool kp = i < n && j < n && (k.sOrd[i] < m || k.sOrd[j] < m);
-            const float scf = fmaxf(fabsf((float)di * (float)dj), kept2s), g2f = gf * gf;
-            float t = 0.f;
-            if (kp && g2f > fmaxf(final2f * scf, 1e-37f)) {
-              const float hyp = __builtin_amdgcn_sqrtf(fmaf(df, df, 4.f * g2f));
-              const float den = df + copysignf(hyp, df);
-              t = den != 0.f ? 2.f * gf * __builtin_amdgcn_rcpf(den) : 0.f;
-              mx_rel = fmaxf(mx_rel, g2f * __builtin_amdgcn_rcpf(scf));
-              mx_t = fmaxf(mx_t, fabsf(t));
-            }
-            Y32[i * ne + j] = t - 0.5f * e;
-            Y32[j * ne + i] = -t - 0.5f * e;
-          } else if (i == j) {
-            Y32[i * ne + i] = first ? -0.5f * E32[i * ne + i] : 0.f;
-          }
-        }
-      mx_rel = wave_max_f32(mx_rel); mx_t = wave_max_f32(mx_t);
-      if ((tid & 63) == 0) {                                      // non-negative floats order like their bit patterns
-        atomicMax(reinterpret_cast<unsigned *>(k.sFlag), __float_as_uint(mx_rel));
-        atomicMax(reinterpret_cast<unsigned *>(k.sFlag) + 1, __float_as_uint(mx_t));
-      }
-      lds_barrier();
-      const unsigned urel = __builtin_amdgcn_readfirstlane(k.sFlag[0]), ut = __builtin_amdgcn_readfirstlane(k.sFlag[1]);
-      dg_t = __uint_as_float(ut); dg_rel = __uint_as_float(urel);
-      if (first) { dg_t0 = dg_t; dg_rel0 = dg_rel; }
-      if (!first && urel == 0u) break;                            // every kept pair meets the criterion
-      if (__uint_as_float(ut) > kMixedMaxT || it >= kMixedMaxIt) { failed = true; break; }
-      // Z = I + Y + Y^2 / 2 -> bD
-      // (float32 matrix pipe: Y is float32 data of size <= kMixedMaxT, so Y^2 / 2 is exact to ~1e-11)
-      mm_lds_f32(ne, ne, ne, Y32, ne, 1, Y32, ne, 1,
-                 [&](int i, int j, float v) { bD[i * ne + j] = 0.5 * (double)v + (double)Y32[i * ne + j] + (i == j ? 1.0 : 0.0); });
-      lds_barrier();
-      // H = K Z -> bB (E and Y are dead)
-      mm_lds(1, ne, ne, ne, bA, 0, ne, 1, bD, 0, ne, 1, [&](int, int i, int j, double v) { bB[i * ne + j] = v; });
-      lds_barrier();
-      // K' = Z^T H -> bA and V' = V Z: independent.  With a fifth buffer (the copy of the matrix the Gram phase read is dead:
-      // bX) they share a level, V' landing in bX; otherwise V' follows into bB once H is dead.  The new basis buffer and the
-      // scratch buffer of the next step swap roles.
-      {
-        const int slot = mm_lds(1, ne, ne, ne, bD, 0, 1, ne, bB, 0, ne, 1,
-                                [&](int, int i, int j, double v) { if (i <= j) { bA[i * ne + j] = v; bA[j * ne + i] = v; } }, true);
-        if (bX) mm_lds(1, ne, ne, ne, bC, 0, ne, 1, bD, 0, ne, 1, [&](int, int i, int j, double v) { bX[i * ne + j] = v; }, false, slot);
-      }
-      lds_barrier();
-      if (bX) {
-        double *tsw = bX; bX = bC; bC = tsw;                     // basis <- V', the old basis buffer becomes the spare
-      } else {
-        mm_lds(1, ne, ne, ne, bC, 0, ne, 1, bD, 0, ne, 1, [&](int, int i, int j, double v) { bB[i * ne + j] = v; });
-        lds_barrier();
-        double *tsw = bB; bB = bC; bC = tsw;
-      }
-      ++refine_its;
-    }
-    if (p.stamps && tid == 0) {
-      const unsigned long long t_m3 = __builtin_amdgcn_s_memtime();
-      p.stamps[34] = (double)rounds32; p.stamps[35] = (double)dg_t0; p.stamps[36] = (double)dg_rel0; p.stamps[37] = (double)refine_its;
-      p.stamps[38] = failed ? 1.0 : 0.0; p.stamps[39] = (double)(t_m1 - t_m0); p.stamps[40] = (double)(t_m2 - t_m1);
-      p.stamps[41] = (double)(t_m3 - t_m2); p.stamps[42] = (double)dg_t; p.stamps[43] = (double)dg_rel; p.stamps[44] = (double)kept2f;
-    }
-    if (!failed) {
-      mixed_done = true;
-      Gfin = bA; Vfin = bC;
-    } else {
-      if (spare_used) {                                           // the Gram operand was the spare buffer: rebuild it from the other copy
-        for (int row = wave_u; row < r; row += NT >> 6)
-          for (int x = tid & 63; x < c; x += 64) {
-            if (short_rows) k.fBp[row * (c + 1) + x] = k.fB[row * c + x]; else k.fB[row * c + x] = k.fBp[row * (c + 1) + x];
-          }
-        lds_barrier();
-      }
-      gram_phase();                                               // the float64 iteration starts from G again
-      scale_phase();
-    }
-  }
-
   // ---- phase 6b: one pivoted-Cholesky step when G is far from diagonal ------------------------------------------
   // G = L L^T (diagonal pivoting), G' = L^T L has the same eigenvalues and is graded: the Jacobi iteration then needs
   // 2-3 sweeps fewer on the merged tensors of the first training passes (off / trace >= 0.25) and the same number
@@ -954,7 +652,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // neutral in the steady state and +2 % cold)
   const double cthr = n >= 32 ? p.chol_thr : fmax(p.chol_thr, kCholThrSmall);
   // (block-uniform: every thread holds the same sums; told to the compiler so that the step below is scalar control flow)
-  const bool use_chol = __builtin_amdgcn_readfirstlane((int)(!mixed_done && chol_possible && off2 > cthr * cthr * tr * tr)) != 0;
+  const bool use_chol = __builtin_amdgcn_readfirstlane((int)(chol_possible && off2 > cthr * cthr * tr * tr)) != 0;
   if (use_chol) {
     for (int e = tid; e < ne * ne; e += NT) Lm[e] = 0.0;
     // The factorisation is bound by LDS traffic, so a worker thread (waves 1..15) owns up to kCholPer fixed PAIRS of
@@ -1159,11 +857,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
         last_big1 = max(last_big1, big_slot);
         ++round_idx;
   };
-  if (mixed_done) {
-    converged = 1;
-    round_idx = rounds32;
-    sweeps = (rounds32 + ne - 2) / (ne - 1);
-  } else if (n > 1) {
+  if (n > 1) {
     kept2 = kept_scale(Gc);
     if (tid == 0) { k.sFlag[6] = 0; k.sFlag[7] = 0; }
     if (isParam) {                                   // rotations of the very first round
@@ -1191,11 +885,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   }
   // the eigenvectors leave the registers: V[row][column position], as phase 9 reads them
   double *V = V0;
-  if (mixed_done) {
-    V = Vfin;
-    Gc = const_cast<double *>(Gfin);
-    Gn = nullptr;
-  } else if (vLaneOk) {
+  if (vLaneOk) {
 #pragma unroll
     for (int r = 0; r < kVR; ++r) {
       const int P = vP0 + r;
@@ -1237,11 +927,6 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       atomicAdd(p.counters + 1, 1ull);
       atomicAdd(p.counters + 2, (unsigned long long)round_idx);
       if (use_chol) atomicAdd(p.counters + 3, 1ull);
-      if (try_mixed) {                                      // float32 stage taken / simultaneous steps / fell back to float64
-        atomicAdd(p.counters + 8, 1ull);
-        atomicAdd(p.counters + 9, (unsigned long long)refine_its);
-        if (!mixed_done) atomicAdd(p.counters + 10, 1ull);
-      }
     }
     if (!converged) atomicOr(p.status, 2);
     if (p.dbg) {

@@ -67,7 +67,6 @@ struct tnml_ctx {
   bool check_launches = false;               // tnml_debug_enable bit 2: read the launch status back after every kernel launch
   int sync_interval = 0;                     // tnml_set_sync_interval: drain the stream every so many steps (0 = never)
   double svd_stop2 = kSvdStop2Default;
-  int mixed_svd = 1;                         // tnml_set_svd_mode: float32 Jacobi + float64 refinement (kernels_narrow.hip phase 7a)
   double chol_thr = kCholThrDefault;         // off(G) / trace(G) above which the pivoted-Cholesky step runs (0 disables it)
   double trunc_thr = 0.999;                  // adaptive truncation threshold (tensor_svd's default argument)
   double prof_ms[4] = {0, 0, 0, 0};
@@ -962,7 +961,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     n.metrics = c->metrics + 2 * (size_t)step;
     n.dbg = (c->debug || mode == 1) ? c->dbg : nullptr;
     n.Bdirect = Bdirect_dev;
-    n.svd_stop2 = c->svd_stop2; n.mixed_svd = c->mixed_svd;
+    n.svd_stop2 = c->svd_stop2;
     n.chol_thr = c->chol_thr;
     n.stop_after_update = mode == 1;
     if (fused) {
@@ -1262,7 +1261,7 @@ extern "C" int tnml_l2_term(tnml_ctx *c, const float *B_canon, int left_dir, flo
   n.Bnew = c->Bscr2;
   n.dbg = c->dbg; n.status = c->status; n.counters = nullptr;
   n.Bdirect = c->Bscr; n.stop_after_update = 1;
-  n.svd_stop2 = c->svd_stop2; n.mixed_svd = c->mixed_svd;
+  n.svd_stop2 = c->svd_stop2;
   rc = run_narrow(c, n, npath);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -1306,7 +1305,7 @@ extern "C" int tnml_svd_split(tnml_ctx *c, const float *mat, int rows, int cols,
   n.dbg = c->dbg; n.status = c->status; n.counters = c->counters;
   n.stamps = (c->debug || c->stamps) ? c->dbg + 4 * c->bmax + kDbgSigma + 5 : nullptr;
   n.Bdirect = c->Bscr;
-  n.svd_stop2 = c->svd_stop2; n.mixed_svd = c->mixed_svd;
+  n.svd_stop2 = c->svd_stop2;
   n.chol_thr = c->chol_thr;
   { int rc = run_narrow(c, n, npath); if (rc) return rc; }
   HIP_TRY(hipGetLastError());
@@ -1510,14 +1509,7 @@ extern "C" int tnml_svd_stats_ex(tnml_ctx *c, int reset, double *out, int capaci
   unsigned long long h[kCounterSlots];
   int rc = read_counters(c, reset, h);
   if (rc) return rc;
-  const int src[7] = {0, 1, 2, 3, 8, 9, 10};
-  for (int i = 0; i < capacity && i < 7; ++i) out[i] = (double)h[src[i]];
-  return TNML_OK;
-}
-
-extern "C" int tnml_set_svd_mode(tnml_ctx *c, int mixed) {
-  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
-  c->mixed_svd = mixed ? 1 : 0;
+  for (int i = 0; i < capacity && i < 4; ++i) out[i] = (double)h[i];
   return TNML_OK;
 }
 

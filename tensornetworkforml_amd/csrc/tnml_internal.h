@@ -20,14 +20,7 @@ constexpr int kDbgSigma = 128;     // capture block: 4 tensors, then this many s
 constexpr double kCholThrSmall = 0.35;     // the same for matrices with n < 32
 constexpr double kCholThrDefault = 0.22;   // off(G)/trace(G) above which the Cholesky step pays off (kernels_narrow.hip phase 6b)
 constexpr double kSvdStop2Default = 1e-6;   // see jacobi_rot (jacobi_device.h) and tnml_set_svd_stop
-// mixed-precision decomposition (kernels_narrow.hip phase 7a): smallest matrix side that takes it, sweeps of its float32 stage,
-// simultaneous float64 steps, largest 2x2 tangent such a step may contain (Z = I + Y + Y^2 / 2 is orthogonal to t^4 / 4)
-constexpr int kMixedMinN = 16;
-constexpr int kMixedMaxSweeps = 10;
-constexpr int kMixedMaxIt = 3;
-constexpr float kMixedMaxT = 0.02f;
-constexpr float kMixedBigScale = 1e-4f;   // float32 stage: "big" rotation = g^2 / (a b) above svd_stop2 * this (1e-10 by default)
-constexpr int kCounterSlots = 16;   // device counters: [0..3] Jacobi statistics, [4..7] fused-launch timing diagnostics, [8..10] mixed path
+constexpr int kCounterSlots = 16;   // device counters: [0..3] Jacobi statistics, [4..7] fused-launch timing diagnostics, [8..] spare
 
 // A plain (label-free) core or the label core addressed in the sweep-relative frame.
 //   plain:  A(in, d, out)      = base[in*s_in + d*s_d + out*s_out]
@@ -94,7 +87,7 @@ struct NarrowParams {
   float *metrics;          // out: (accuracy, MAE) of this step
   double *dbg;             // debug block (see narrow kernel), may be nullptr
   double *stamps;          // cycle stamps (diagnostic), may be nullptr
-  unsigned long long *counters;  // [0] += jacobi sweeps, [1] += SVDs, [2] += jacobi rounds, [3] Cholesky steps, [8] mixed-precision SVDs, [9] their float64 steps, [10] fallbacks (always on)
+  unsigned long long *counters;  // [0] += jacobi sweeps, [1] += SVDs, [2] += jacobi rounds, [3] Cholesky steps (always on)
   const float *Bdirect;    // if set: the merged tensor (relative layout) is given, the two cores are not read
   int stop_after_update;   // 1: return after B_new (standalone update_B / compute_L2_reg; needs dbg)
   // fused launch (single GPU, in-LDS path): workgroups 1.. of the same launch reduce the gradient slabs and
@@ -112,7 +105,6 @@ struct NarrowParams {
   int *m_out;              // device int receiving the kept rank (adaptive truncation), may be nullptr
   double chol_thr;         // > 0: one pivoted-Cholesky step before the Jacobi iteration when off(G) / trace(G) exceeds it
   double svd_stop2;        // Jacobi stops after a sweep whose rotations all had g^2 / scale^2 <= svd_stop2 (tnml_set_svd_stop)
-  int mixed_svd;           // 1: float32 Jacobi + float64 simultaneous refinement where it applies (kernels_narrow.hip phase 7a)
   int *status;             // device status word: bit0 non-finite, bit1 jacobi not converged, bit2 helpers late, bit3 flag never seen
   int wait_count;          // fused / pipelined launch: helper arrivals workgroup 0 waits for on `sync`
   // pipelined step (wide_pipe_device.h): the raw gradient is A_{k-1}^T . Z_k, Z_k reduced by the previous launch
