@@ -170,6 +170,13 @@ int tnml_set_svd_stop(tnml_ctx *ctx, double stop2);
  * whose SVD is long enough to hide that (short side >= 32); on = 1 means the default, 2. */
 int tnml_set_step_pipeline(tnml_ctx *ctx, int on);
 
+/* A FULL sweep (n_steps = N-1 right after tnml_forward) on a single GPU under the fixed or the reference truncation is ONE launch by
+ * default: a persistent kernel whose update workgroup, helper workgroup and batch-side workgroups each loop over the N-1 steps and
+ * hand their results to each other through flags in memory.  Sweeps it does not cover (partial sweeps, a
+ * communicator, adaptive truncation, per-step capture, merged tensors beyond one workgroup's LDS) take one launch per step as
+ * before.  on = 0 forces the per-step launches everywhere. */
+int tnml_set_persistent(tnml_ctx *ctx, int on);
+
 /* tnml_sweep enqueues every launch of its n_steps steps without waiting (2 - 14 launches per step).  A profiler that
  * intercepts dispatches (rocprofv3 --pmc serialises them and keeps per-dispatch state) can be overrun by tens of
  * thousands of queued launches; n_steps > 0 drains the stream every n_steps steps, 0 (default) never. */

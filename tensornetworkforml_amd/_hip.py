@@ -28,7 +28,7 @@ SYMBOLS = [
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
     'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict', 'tnml_set_trunc_threshold',
     'tnml_set_sync_interval', 'tnml_set_step_pipeline', 'tnml_stage_batch', 'tnml_select_batch', 'tnml_get_counters',
-    'tnml_svd_stats_ex',
+    'tnml_svd_stats_ex', 'tnml_set_persistent',
 ]
 
 
@@ -85,6 +85,7 @@ def lib():
         L.tnml_profile_reset.argtypes = [vp]
         L.tnml_svd_stats.argtypes = [vp, C.c_int, f64p]
         L.tnml_svd_stats_ex.argtypes = [vp, C.c_int, f64p, C.c_int]
+        L.tnml_set_persistent.argtypes = [vp, C.c_int]
         L.tnml_trunc_rank.argtypes = [C.c_int] * 9
         L.tnml_update_B.argtypes = [vp, f32p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float,
                                     f64p, C.c_size_t, f32p]
@@ -333,6 +334,10 @@ class Context:
     def set_step_pipeline(self, on):
         """True (default): one launch per sweep step (pipelined); False: the classic launch sequence."""
         _chk(lib().tnml_set_step_pipeline(self._h, int(on)))
+
+    def set_persistent(self, on=True):
+        """True (default): a full sweep is ONE persistent launch where it applies; False: one launch per step everywhere."""
+        _chk(lib().tnml_set_persistent(self._h, int(bool(on))))
 
     def set_sync_interval(self, n_steps):
         """Drain the stream every n_steps sweep steps (0: never); for runs under a dispatch-intercepting profiler."""

@@ -168,7 +168,11 @@ __device__ inline void narrow_helper_block(const NarrowParams &p, unsigned char 
   }
 }
 
-__device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char *smem_raw) {
+// returns true when a wait of a persistent sweep timed out (the caller leaves its step loop)
+// NP: NarrowParams (kernel argument) or its constant-address-space twin (persistent sweep: the per-step records are read with scalar
+// loads only if the compiler knows nothing in the kernel writes them)
+template <class NP>
+__device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw) {
   // value ranges the launcher guarantees (narrow_lds_bytes / narrow_path): with them the compiler turns the index products into
   // full-rate 24-bit multiplies (a 32-bit v_mul_lo_u32 issues at quarter rate, and this workgroup is issue-bound)
   __builtin_assume(p.h >= 1 && p.h <= 64 && p.g >= 1 && p.g <= 64 && p.s >= 1 && p.s <= 128 && p.m >= 1 && p.m <= 64);
@@ -184,7 +188,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   };
   // metric sums of the batch-side workgroups: behind the gradient (classic) or behind the reduced pre-gradient (pipelined)
   // (pipelined: read NOW -- the batch-side workgroups of this launch overwrite zred once B_new is published)
-  if (p.pipe && threadIdx.x == 0)
+  if (p.pipe && !p.persist && threadIdx.x == 0)
     for (int i = 0; i < kMetricSlots; ++i) k.sTail[i] = p.zred[p.zsize + i];      // LDS: the loads complete here
   auto ldtail = [&](int i) -> float { return p.pipe ? k.sTail[i] : ldred(p.bsize + i); };
   const int r = D * h, c = D * g * L;
@@ -201,8 +205,79 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   // Pipelined launch whose merged tensor / L2 term were prepared by the previous launch's tail: EVERY global operand of
   // this workgroup is requested at once (16-byte loads where the layout allows) and lands in LDS after one round trip --
   // a loop of dependent load -> LDS-store iterations costs one round trip per iteration (7 for the reduced pre-gradient).
-  const bool fast0 = p.pipe && (size_t)p.z_rows * RWz + (size_t)p.z_rows * h <= (size_t)((float *)k.sOrd - k.fBp) &&
+  const bool fast0 = p.pipe && !p.persist && (size_t)p.z_rows * RWz + (size_t)p.z_rows * h <= (size_t)((float *)k.sOrd - k.fBp) &&
                      Bs <= 8 * NT && p.z_rows * RWz <= 16 * NT && p.z_rows * h <= 4 * NT && h * h <= 2 * NT && g * g <= 2 * NT;
+  // ---- persistent sweep: merged tensor and raw gradient of this step as projections with the previous step's behind core ----
+  //   B_k      = diag(1 / sigma) A'^T . T_k,   T_k[i, d, d', g, l] = sum_s B_new(k-1)[i, d, s, l] pl_{k+1}[s, d', g]   (helper workgroup)
+  //   dB_raw_k =                 A'^T . Z_k                                                                       (batch-side workgroups)
+  // A' = U sqrt(S) [D h_{k-1}][h] and 1 / sigma stay in LDS from the end of step k-1 (identity at k == 0, where T_0 = A_0 . A_1 and
+  // Z_0 is the gradient itself).  The right-hand operands go from memory straight into the MFMA operand registers (agent-scope
+  // loads, every k-step of a column tile in flight at once): no staging, one barrier.
+  const PersistLds PL = persist_lds(smem_raw + p.persist_off, p.Mcap);
+  float *sRaw = k.fBp;                          // raw gradient [h][RW] (float): dead before phase 5 rewrites fBp
+  if (p.persist) {
+    if (tid == 0) {
+      int bad = spin_wait_ge(p.zready, p.zwant, p.abort_flag);
+      if (!bad) bad = spin_wait_ge(p.tready, p.twant, p.abort_flag);
+      if (bad == 1) { atomicOr(p.status, 4); __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      k.sFlag[3] = bad;
+    }
+    lds_barrier();
+    if (k.sFlag[3]) return true;
+    if (tid < kMetricSlots) k.sTail[tid] = ld_sc1(p.zred + p.zsize + tid);
+    for (int e = tid; e < h * h; e += NT) k.dNh[e] = p.Nh ? PL.Nh[e] : 1.0;
+    for (int e = tid; e < g * g; e += NT) k.dNg[e] = p.Ng ? p.Ng[e] : 1.0;
+    const int zr = p.zr, RW = RWz;
+    const int lane = tid & 63, rr = lane & 15, qq = lane >> 4;
+    const int ncol = (RW + 15) >> 4, nk = (zr + 3) >> 2, tmh = (h + 15) >> 4;
+    constexpr int kMaxK = 16;                    // zr <= 64 (launcher)
+    for (int item = wave_u; item < 2 * ncol; item += NT >> 6) {
+      const bool isT = item >= ncol;
+      const int ct = isT ? item - ncol : item;
+      const float *S = isT ? p.Tsrc : p.zred;
+      const int col = min(ct * 16 + rr, RW - 1);
+      float bv[kMaxK];
+#pragma unroll
+      for (int ks = 0; ks < kMaxK; ++ks) {
+        const int row = 4 * ks + qq;
+        bv[ks] = (ks < nk && row < zr) ? ld_sc1(S + (size_t)row * RW + col) : 0.f;
+      }
+      for (int ti = 0; ti < tmh; ++ti) {
+        const int hh = min(ti * 16 + rr, h - 1);
+        if (!isT) {
+          fvec4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < kMaxK; ++ks) {
+            if (ks >= nk) break;
+            const int row = 4 * ks + qq;
+            const float a = row < zr ? PL.A[row * h + hh] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[ks], acc, 0, 0, 0);
+          }
+          const int j = ct * 16 + rr;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int i = ti * 16 + 4 * qq + reg;
+            if (i < h && j < RW) sRaw[i * RW + j] = acc[reg];
+          }
+        } else {
+          dvec4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < kMaxK; ++ks) {
+            if (ks >= nk) break;
+            const int row = 4 * ks + qq;
+            const double a = row < zr ? (double)PL.A[row * h + hh] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (double)bv[ks], acc, 0, 0, 0);
+          }
+          const int j = ct * 16 + rr;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int i = ti * 16 + qq + 4 * reg;
+            if (i < h && j < RW) k.fB[i * RW + j] = (float)(acc[reg] * PL.invs[i]);
+          }
+        }
+      }
+    }
+  }
   float *sZ = k.fBp, *sZc = sZ + (size_t)p.z_rows * RWz;
   if (fast0) {
     const int zr = p.z_rows, nz = p.z_first ? 0 : zr * RWz, nzc = p.z_first ? 0 : zr * h;
@@ -274,7 +349,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const int e = 2 * (tid + u * NT); if (p.l2_flag && e < Bs) *reinterpret_cast<tn_uvec4 *>(k.dG + e) = qg[u]; }
     }
-  } else if (p.pipe && !p.z_first) {
+  } else if (p.pipe && !p.persist && !p.z_first) {
     const float *zc = p.zcore.base;
     const int zs_in = p.zcore.s_in, zs_d = p.zcore.s_d, zs_out = p.zcore.s_out;
     const int zr = p.z_rows;
@@ -284,7 +359,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
                    [&](int, int i, int j, double v) { k.dT[i * RWz + j] = v; });
   }
   // ---- phase 0: stage the two cores and the norm environments ---------------------------------
-  if (fast0) {
+  if (fast0 || p.persist) {
     // everything is in LDS already
   } else if (p.fused) {
     // B and Ln.B.Rn come from the slice workgroups of the preceding wide launch (prep_ready: plain loads, issued
@@ -340,7 +415,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   } else {
     for (int e = tid; e < Bs; e += NT) k.fB[e] = p.Bdirect[e];
   }
-  if (!fast0) {
+  if (!fast0 && !p.persist) {
     for (int e = tid; e < h * h; e += NT) k.dNh[e] = p.Nh ? p.Nh[e] : 1.0;
     for (int e = tid; e < g * g; e += NT) k.dNg[e] = p.Ng ? p.Ng[e] : 1.0;
   }
@@ -349,7 +424,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   TNML_STAMP(0);
   // ---- phase 1: B[h,dk,dk1,g,l] = sum_s lab(h,dk,s,l) * pl(s,dk1,g) ---------------------------
   const int RW = D * D * g * L;  // elements per behind-bond index
-  if (!p.Bdirect && !p.fused && !p.prep_ready) {   // rows i = (h_, dk, l), columns j = (dk1, g_), inner index the shared bond
+  if (!p.Bdirect && !p.fused && !p.prep_ready && !p.persist) {   // rows i = (h_, dk, l), columns j = (dk1, g_), inner index the shared bond
     const int QW = D * g;
     small_gemm_f64(L, h * D, QW, s,
                    [&](int l, int i, int kk) { return (double)k.sLab[(i * s + kk) * L + l]; },
@@ -381,14 +456,14 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
 #pragma unroll
   for (int u = 0; u < kMaxPer; ++u) {                     // all loads of the reduced gradient in flight together
     const int e = tid + u * NT;
-    redv[u] = (e < Bs && !(p.pipe && !p.z_first)) ? ldred(e) : 0.f;
+    redv[u] = (e < Bs && !p.persist && !(p.pipe && !p.z_first)) ? ldred(e) : 0.f;
   }
 #pragma unroll
   for (int u = 0; u < kMaxPer; ++u) {
     const int e = tid + u * NT;
     if (e >= Bs) break;
     const double bv = (double)k.fB[e];
-    const double raw = (p.pipe && !p.z_first) ? k.dT[e] : (double)redv[u];
+    const double raw = p.persist ? (double)sRaw[e] : ((p.pipe && !p.z_first) ? k.dT[e] : (double)redv[u]);
     double wdterm;
     if (p.l2_flag) {
       const double gv = k.dG[e];
@@ -469,7 +544,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
       p.metrics[0] = (float)((double)ldtail(0) * inv);
       p.metrics[1] = (float)((double)ldtail(1) * inv / (double)L);
     }
-    return;
+    return false;
   }
 
   TNML_STAMP(3);
@@ -961,6 +1036,8 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     if (!p.left_dir) { ob_s_h = D * mk; ob_s_d = mk; } else { oa_s_d = mk * L; oa_s_g = D * mk * L; }
   }
   // ---- phase 9: the two new cores -----------------------------------------------------------------
+  // (persistent sweep: the batch-side workgroups of this launch extend their environments with the behind core -> agent scope)
+  auto st_behind = [&](int off, float v) { if (p.persist) st_sc1(p.out_behind + off, v); else p.out_behind[off] = v; };
   const double lam_max = k.dLam[k.sOrd[0]];
   for (int sp = tid; sp < mk; sp += NT) {                 // sigma^(+-1/2) once per kept column (lam = sigma^2)
     const double lam = k.dLam[k.sOrd[sp]];
@@ -981,7 +1058,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     k.dVs[kk * mk + sp] = vq * k.dSq[ne + sp];
     if (short_rows) {                       // kk = row index i = h_*D + dk  -> behind core
       k.sCb[kk * mk + sp] = v;
-      p.out_behind[(kk / D) * ob_s_h + (kk % D) * ob_s_d + sp * p.ob_s_m] = v;
+      st_behind((kk / D) * ob_s_h + (kk % D) * ob_s_d + sp * p.ob_s_m, v);
     } else {                                // kk = column index (dk1*g + g_)*L + l -> ahead core
       const int l = kk % L, q = kk / L;
       p.out_ahead[sp * p.oa_s_m + (q / g) * oa_s_d + (q % g) * oa_s_g + l] = v;
@@ -995,7 +1072,11 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
   auto store_T2 = [&](int, int i, int j, double v) { k.dT2[i * DM + j] = v; };
   if (short_rows) {
     // long index = ahead group x = (dk1, g_, l) = qq * L + l: the label is the batch, rows are qq = (dk1, g_)
-    const int slot = mm_lds(L, D * g, mk, n, k.fB, 1, L, c, k.dVs, 0, mk, 1,
+    // (persistent sweep: the next step forms its merged tensor from T_{k+1} and this step's behind core, so the new label core
+    // is only computed where somebody reads it -- at the last step of the launch)
+    int slot = 0;
+    if (!p.persist || p.write_ahead)
+      slot = mm_lds(L, D * g, mk, n, k.fB, 1, L, c, k.dVs, 0, mk, 1,
            [&](int l, int qq, int sp, double acc) {
              const int dk1 = qq >= g ? 1 : 0;                     // D == 2
              p.out_ahead[__mul24(sp, p.oa_s_m) + dk1 * oa_s_d + __mul24(qq - dk1 * g, oa_s_g) + l] = (float)acc;
@@ -1008,7 +1089,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
            [&](int dk, int h_, int sp, double acc) {
              const float v = (float)acc;
              k.sCb[__mul24(h_ * D + dk, mk) + sp] = v;
-             p.out_behind[__mul24(h_, ob_s_h) + dk * ob_s_d + __mul24(sp, p.ob_s_m)] = v;
+             st_behind(__mul24(h_, ob_s_h) + dk * ob_s_d + __mul24(sp, p.ob_s_m), v);
            });
   }
   lds_barrier();
@@ -1022,7 +1103,7 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     }
     // Nh_new[s', s''] = sum_{(h_, d)} Cb[(h_, d), s'] T2[(h_, d), s'']
     mm_lds(1, mk, mk, h * D, k.sCb, 0, 1, mk, k.dT2, 0, mk, 1,
-           [&](int, int i, int j, double v) { p.Nh_new[i * mk + j] = v; });
+           [&](int, int i, int j, double v) { p.Nh_new[i * mk + j] = v; if (p.persist) PL.Nh[i * mk + j] = v; });
   }
 
   if (p.stamps && tid == 0) {
@@ -1045,6 +1126,17 @@ __device__ __forceinline__ void narrow_body(const NarrowParams &p, unsigned char
     p.metrics[1] = (float)((double)ldtail(1) * inv / (double)L);
     if (ldtail(2) != 0.f) atomicOr(p.status, 1);
   }
+  if (p.persist) {
+    // what the next step of the sweep needs from this one stays in LDS: the behind core, 1 / sigma, (the norm environment went there
+    // from its product); the behind core in memory is complete once every storing wave has drained -> flag for the batch side
+    lds_barrier();                                           // sCb complete (long-side product of the !short_rows case)
+    for (int e = tid; e < r * mk; e += NT) PL.A[e] = k.sCb[e];
+    for (int sp = tid; sp < mk; sp += NT) { const double iq = k.dSq[ne + sp]; PL.invs[sp] = iq * iq; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (tid == 0) __hip_atomic_store(p.coreflag, p.coretoken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return false;
 }
 
 // classic step: one narrow launch (workgroup 0 + optional reduce / slice helpers)
@@ -1073,6 +1165,104 @@ __global__ __launch_bounds__(kNarrowThreads) void step_pipe_kernel(NarrowParams 
 void launch_step_pipe(const NarrowParams &p, const WidePipeParams &w, size_t lds_bytes, hipStream_t st) {
   const int grid = w.wg0 + (w.do_f || w.do_z || w.do_ext ? w.nwide : 0);
   hipLaunchKernelGGL(step_pipe_kernel, dim3(grid), dim3(kNarrowThreads), lds_bytes, st, p, w);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent sweep: ONE launch per sweep (single GPU, every step in the in-LDS regime, bond dimensions known in advance).
+//   workgroup 0      update + SVD of step k, k = 0 .. n_steps-1 (narrow_body in its persistent mode)
+//   workgroup 1      T_k = B_new(k-1) . A_{k+1} (the merged tensor of step k before the projection onto the new bond), formed
+//                    beside the SVD of step k-1
+//   workgroups 2..   the batch-side workgroups of the pipelined step (wide_pipe_block), each looping over the steps with its own
+//                    samples: Z_0 from forward's f first, then per step: extend E with the new behind core, f from B_new(k), Z_{k+1}
+// Against one launch per step this removes, from the critical path of every step: the launch itself, the fetch of a 900-byte
+// argument block and of operands another launch wrote, and the slice helpers' two dependent product levels.
+// All hand-offs follow the first row of the hand-off table of MI355X_MICROARCH.md (agent-scope stores, drained, barrier, one-lane
+// flag; relaxed poll, barrier, agent-scope loads) on flags that only grow; every wait is bounded and gives up for the whole
+// launch through one abort word, so the grid always drains.
+// ------------------------------------------------------------------------------------------------------------------
+template <class HP>
+__device__ inline bool persist_helper_block(const HP &t, unsigned char *smem_raw) {
+  const int tid = threadIdx.x, NT = kNarrowThreads;
+  const int D = kD, zr = t.zr, s = t.s, g = t.g, L = t.L;
+  float *sW = (float *)smem_raw;                           // [zr D][s][L]   rows (i, d) of W_{k-1}
+  const int nW = zr * D * s * L, nP = s * D * g, nT = zr * D * D * g * L;
+  float *sP = sW + ((nW + 3) & ~3);                        // [s][D g]       A_{k+1}(s, (d', g))
+  float *oT = sP + ((nP + 3) & ~3);                        // [zr D][D g][L] the result, staged for 16-byte stores
+  __shared__ int sBad;
+  if (tid == 0) {
+    const int bad = t.want ? spin_wait_ge(t.flag, t.want, t.abort_flag) : 0;
+    if (bad == 1) { atomicOr(t.status, 4); __hip_atomic_store(t.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    sBad = bad;
+  }
+  lds_barrier();
+  if (sBad) return true;
+  if (t.W) {                                               // B_new(k-1), stored by the update workgroup of this launch
+    if ((nW & 3) == 0) {
+      const __amdgpu_buffer_rsrc_t rW = sc1_rsrc(t.W);
+      for (int e = 4 * tid; e < nW; e += 4 * NT) *reinterpret_cast<tn_uvec4 *>(sW + e) = ld_sc1_b128(rW, (unsigned)e * 4u);
+    } else {
+      for (int e = tid; e < nW; e += NT) sW[e] = ld_sc1(t.W + e);
+    }
+  } else {                                                 // k == 0: the label core itself, (d, s, l)
+    for (int e = tid; e < nW; e += NT) {
+      const int l = e % L, q = e / L, s_ = q % s, d = q / s;
+      sW[e] = t.lab.base[d * t.lab.s_d + s_ * t.lab.s_out + l];
+    }
+  }
+  for (int e = tid; e < nP; e += NT) {
+    const int g_ = e % g, q = e / g, d = q % D, s_ = q / D;
+    sP[e] = t.pl.base[s_ * t.pl.s_in + d * t.pl.s_d + g_ * t.pl.s_out];
+  }
+  lds_barrier();
+  const int DG = D * g;
+  mm_lds(L, zr * D, DG, s, sW, 1, s * L, L, sP, 0, DG, 1,
+         [&](int l, int row, int col, double v) { oT[(row * DG + col) * L + l] = (float)v; });
+  lds_barrier();
+  if ((nT & 3) == 0) {
+    const __amdgpu_buffer_rsrc_t rT = sc1_rsrc(t.T);
+    for (int e = 4 * tid; e < nT; e += 4 * NT) st_sc1_b128(rT, (unsigned)e * 4u, *reinterpret_cast<const tn_uvec4 *>(oT + e));
+  } else {
+    for (int e = tid; e < nT; e += NT) st_sc1(t.T + e, oT[e]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
+  if (tid == 0) __hip_atomic_store(t.tready, t.publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+typedef const __attribute__((address_space(4))) PersistStep ConstPersistStep;
+typedef const __attribute__((address_space(4))) WidePipeParams ConstWidePipeParams;
+__global__ __launch_bounds__(kNarrowThreads) void sweep_persist_kernel(const PersistStep *__restrict__ steps_g,
+                                                                       const WidePipeParams *__restrict__ pro_g, int n_steps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // the host wrote the records before the launch and nothing in the kernel writes them: constant address space -> scalar loads
+  ConstPersistStep *steps = (ConstPersistStep *)steps_g;
+  ConstWidePipeParams *pro = (ConstWidePipeParams *)pro_g;
+  const int blk = blockIdx.x;
+  if (blk == 0) {
+    const PersistLds PL = persist_lds(smem_raw + steps[0].n.persist_off, steps[0].n.Mcap);
+    if (threadIdx.x == 0) { PL.A[0] = 1.f; PL.invs[0] = 1.0; PL.Nh[0] = 1.0; }     // step 0 projects with the identity
+    lds_barrier();
+#pragma nounroll
+    for (int k = 0; k < n_steps; ++k)
+      if (narrow_body(steps[k].n, smem_raw)) break;
+  } else if (blk == 1) {
+#pragma nounroll
+    for (int k = 0; k < n_steps; ++k)
+      if (persist_helper_block(steps[k].t, smem_raw)) break;
+  } else {
+    if (wide_pipe_block(*pro, (float *)smem_raw)) return;
+#pragma nounroll
+    for (int k = 0; k < n_steps; ++k) {
+      lds_barrier();                                       // the previous step's LDS arrays are dead
+      if (wide_pipe_block(steps[k].w, (float *)smem_raw)) break;
+    }
+  }
+}
+
+void launch_sweep_persist(const PersistStep *steps_dev, const WidePipeParams *pro_dev, int n_steps, int grid, size_t lds_bytes,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(sweep_persist_kernel, dim3(grid), dim3(kNarrowThreads), lds_bytes, st, steps_dev, pro_dev, n_steps);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -112,6 +112,17 @@ struct tnml_ctx {
   int Z_k = -1, Z_left = 0, Z_act = 0, Z_loss = 0;
   float Z_T = 0.f;
   unsigned token = 0;
+  // persistent sweep (sweep_persist_kernel): per-step records (device + two pinned host staging buffers), second buffers of the
+  // reduced pre-gradient, T_k buffers, per-step arrival counters, the flag words of the launch
+  bool persist_enabled = true;               // tnml_set_persistent
+  PersistStep *pst_dev = nullptr, *pst_host[2] = {nullptr, nullptr};
+  WidePipeParams *pro_dev = nullptr, *pro_host[2] = {nullptr, nullptr};
+  hipEvent_t pst_ev[2] = {nullptr, nullptr};
+  int pst_cur = 0;
+  float *zred2 = nullptr, *Tbuf[2] = {nullptr, nullptr};
+  unsigned *pst_cnt = nullptr, *pst_flags = nullptr;
+  long long persist_sweeps = 0;
+  int num_cus = 256;
   float *Xpred_stage = nullptr, *Xpred = nullptr, *fpred = nullptr;   // tnml_predict's own batch (the resident one is untouched)
   int pred_cap = 0;
   int slab_stride = 0, nblk_cap = 0, metrics_cap = 0;
@@ -163,8 +174,8 @@ static int alloc_batch_buffers(tnml_ctx *c, int b_cap) {
   HIP_TRY(hipMalloc(&c->Renv, env_elems * sizeof(float)));
   c->nblk_cap = b_pad / kTS;
   HIP_TRY(hipMalloc(&c->slabs, (size_t)c->nblk_cap * c->slab_stride * sizeof(float)));
-  {   // batch-side workgroups of the pipelined step: at most kPipeMaxWide, each looping over pipe_tpw sample tiles
-    constexpr int kPipeMaxWide = 240;
+  {   // batch-side workgroups of the pipelined step: at most kPipeMaxWide (from the device's CU count), each looping over pipe_tpw sample tiles
+    const int kPipeMaxWide = std::max(16, c->num_cus - 16);      // + update workgroup and its helpers: all resident, one per CU
     const int ntiles = b_pad / kTS;
     c->pipe_tpw = (ntiles + kPipeMaxWide - 1) / kPipeMaxWide;
     c->pipe_nwide = (ntiles + c->pipe_tpw - 1) / c->pipe_tpw;
@@ -201,6 +212,7 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   c->Mpol = Mmax;
   Mmax = std::max(Mmax, D * std::min(L, Mmax));
   c->N = N; c->D = D; c->L = L; c->Mmax = Mmax; c->device = device;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->bond.assign(N - 1, 1);
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -228,6 +240,18 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipMalloc(&c->zred, (size_t)c->zstride * sizeof(float)));
   HIP_TRY(hipMalloc(&c->pipe_cnt, 32 * sizeof(unsigned)));
   HIP_TRY(hipMemset(c->pipe_cnt, 0, 32 * sizeof(unsigned)));
+  HIP_TRY(hipMalloc(&c->zred2, (size_t)c->zstride * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->Tbuf[0], (size_t)c->zstride * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->Tbuf[1], (size_t)c->zstride * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->pst_dev, (size_t)N * sizeof(PersistStep)));
+  HIP_TRY(hipMalloc(&c->pro_dev, sizeof(WidePipeParams)));
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipHostMalloc(&c->pst_host[i], (size_t)N * sizeof(PersistStep)));
+    HIP_TRY(hipHostMalloc(&c->pro_host[i], sizeof(WidePipeParams)));
+    HIP_TRY(hipEventCreateWithFlags(&c->pst_ev[i], hipEventDisableTiming));
+  }
+  HIP_TRY(hipMalloc(&c->pst_cnt, (size_t)(N + 1) * 32 * sizeof(unsigned)));
+  HIP_TRY(hipMalloc(&c->pst_flags, 8 * sizeof(unsigned)));
   HIP_TRY(hipMalloc(&c->Bscr2, c->bmax * sizeof(float)));
   HIP_TRY(hipMalloc(&c->red, (size_t)c->slab_stride * sizeof(float)));
   c->metrics_cap = N;
@@ -257,6 +281,13 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
                   c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2,
                   c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->zslabs, c->gslabs, c->zred, c->pipe_cnt, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
   for (void *p : ptrs) if (p) (void)hipFree(p);
+  void *pptrs[] = {c->zred2, c->Tbuf[0], c->Tbuf[1], c->pst_dev, c->pro_dev, c->pst_cnt, c->pst_flags};
+  for (void *p : pptrs) if (p) (void)hipFree(p);
+  for (int i = 0; i < 2; ++i) {
+    if (c->pst_host[i]) (void)hipHostFree(c->pst_host[i]);
+    if (c->pro_host[i]) (void)hipHostFree(c->pro_host[i]);
+    if (c->pst_ev[i]) (void)hipEventDestroy(c->pst_ev[i]);
+  }
   for (int i = 0; i < tnml_ctx::kStageSlots; ++i) { if (c->stageX[i]) (void)hipFree(c->stageX[i]); if (c->stageY[i]) (void)hipFree(c->stageY[i]); }
   for (hipEvent_t e : c->sweep_ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -850,6 +881,157 @@ static void fill_prev_operands(tnml_ctx *c, WideParams &w, int left_dir, int p_p
   w.Bprev = c->Bnew;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent sweep: the whole sweep as ONE launch of sweep_persist_kernel (kernels_narrow.hip).  Applies to a full sweep that
+// starts right after tnml_forward on a single GPU, fixed or reference truncation (all bond dimensions are known before the
+// launch), every step in the in-LDS regime, no per-step capture.  Plans every step exactly as the per-step path does (the
+// records ARE its NarrowParams / WidePipeParams, plus the hand-off fields), so the host bookkeeping -- bonds, label position,
+// label-core buffer -- advances through the same statements.  Returns 1 if the sweep was enqueued, 0 if this sweep has to take
+// the per-step path (state untouched), < 0 on error.
+// ---------------------------------------------------------------------------------------------
+static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float weight_dec, int l2_flag, int act_fn, int loss_fn,
+                         float T, int trunc_policy) {
+  const int N = c->N, D = c->D, L = c->L;
+  if (!c->persist_enabled || !c->pipe_enabled || c->comm || c->debug || c->stamps || c->profile || c->check_launches) return 0;
+  if (trunc_policy == TNML_TRUNC_ADAPTIVE || n_steps != N - 1 || c->force_big) return 0;
+  if (!c->f_current || c->Bnew_valid) return 0;
+  // state the planning loop advances; restored if some step does not fit
+  const std::vector<int> bond0 = c->bond;
+  const int l_pos0 = c->l_pos, lab_cur0 = c->lab_cur;
+  auto give_up = [&]() { c->bond = bond0; c->l_pos = l_pos0; c->lab_cur = lab_cur0; return 0; };
+  const int buf = c->pst_cur;
+  HIP_TRY(hipEventSynchronize(c->pst_ev[buf]));              // the copy that last read this staging buffer is done
+  PersistStep *st = c->pst_host[buf];
+  WidePipeParams &pro = *c->pro_host[buf];
+  double *nbeh = left_dir ? c->Rn : c->Ln, *nahe = left_dir ? c->Ln : c->Rn;
+  const int ntiles = c->b_pad / kTS;
+  const int tpw = ntiles >= 64 ? std::max(c->pipe_tpw, c->pipe_tiles) : c->pipe_tpw;
+  const int nwide = (ntiles + tpw - 1) / tpw;
+  if (2 + nwide > c->num_cus) return 0;                      // every workgroup of the launch must be resident
+  const int Mcap = c->Mmax;
+  const size_t pbytes = persist_lds_bytes(Mcap);
+  unsigned *fl = c->pst_flags;                               // [0] B_new token, [1] T ready, [2] Z ready, [3] behind core stored, [4] abort
+  float *zr2[2] = {c->zred, c->zred2};
+  size_t lds_narrow = 0, lds_wide = 0, lds_help = 0;
+  // prologue: Z_0 from forward's f
+  fill_wide_pipe(c, pro, left_dir, -1, act_fn, loss_fn, T);
+  pro.do_ext = 0; pro.wait_flag = 0; pro.do_z = 1; pro.do_f = 0;
+  pro.tiles_per_wg = tpw; pro.nwide = nwide; pro.ngroups = (nwide + kPipeGroupMax - 1) / kPipeGroupMax; pro.gsz = kPipeGroupMax;
+  pro.wg0 = 2; pro.persist = 1; pro.zred = zr2[0]; pro.zready = fl + 2; pro.zpublish = 1; pro.abort_flag = fl + 4;
+  pro.gcnt = c->pst_cnt + (size_t)n_steps * 32; pro.tcnt = pro.gcnt + 16;
+  if (!wide_pipe_fits(c, pro)) return give_up();
+  if (pro.nwide <= 256 && (size_t)16 * (pro.zsize + kMetricSlots) * sizeof(float) <= wide_pipe_lds_bytes(pro) - 16) { pro.gsz = pro.nwide; pro.ngroups = 1; pro.one_level = 1; }
+  lds_wide = wide_pipe_lds_bytes(pro);
+  double bytes = 0, flops = 0;
+  for (int k = 0; k < n_steps; ++k) {
+    const int l = c->l_pos;
+    const int p = left_dir ? l - 1 : l;
+    const int sb = left_dir ? p + 1 : p, sa = left_dir ? p : p + 1;
+    const int h = left_dir ? c->mr(p + 1) : c->ml(p);
+    const int g = left_dir ? c->ml(p) : c->mr(p + 1);
+    const int s = c->bond[p];
+    const int m = tnml_trunc_rank(trunc_policy, left_dir, p, N, c->ml(p), D, c->mr(p + 1), L, c->Mpol);
+    if (m < 0) return give_up();                             // the per-step path reports the reference's ValueError
+    const size_t bsize = (size_t)h * D * D * g * L;
+    if (bsize > c->bmax || m > c->Mmax || (size_t)h * D * m > c->core_stride || (size_t)m * D * g * L > c->lab_elems) return give_up();
+    const int r = D * h, cc = D * g * L, nn = std::min(r, cc);
+    const size_t nlds = narrow_lds_bytes(h, g, s, L, m);
+    if (nn > 64 || (nn & 1) || nlds + pbytes > 160 * 1024 || h > Mcap || m > Mcap || bsize > 8192) return give_up();
+    PersistStep &ps = st[k];
+    ps = PersistStep{};
+    // ---- update + SVD workgroup
+    NarrowParams &n = ps.n;
+    n.L = L; n.D = D; n.h = h; n.g = g; n.s = s; n.m = m; n.bsize = (int)bsize;
+    n.l2_flag = l2_flag ? 1 : 0; n.lr = lr; n.wd = weight_dec;
+    n.pl.base = c->core_slot(sa); n.pl.n_in = s; n.pl.n_out = g;
+    n.lab.base = c->lab[c->lab_cur]; n.lab.n_in = h; n.lab.n_out = s;
+    if (!left_dir) {
+      n.lab.s_in = D * s * L; n.lab.s_d = s * L; n.lab.s_out = L;
+      n.pl.s_in = D * g; n.pl.s_d = g; n.pl.s_out = 1;
+      n.ob_s_h = D * m; n.ob_s_d = m; n.ob_s_m = 1;
+      n.oa_s_m = D * g * L; n.oa_s_d = g * L; n.oa_s_g = L;
+    } else {
+      n.lab.s_in = L; n.lab.s_d = h * L; n.lab.s_out = D * h * L;
+      n.pl.s_in = 1; n.pl.s_d = s; n.pl.s_out = D * s;
+      n.ob_s_h = 1; n.ob_s_d = h; n.ob_s_m = D * h;
+      n.oa_s_m = L; n.oa_s_d = m * L; n.oa_s_g = D * m * L;
+    }
+    {
+      const int bs_ = left_dir ? p + 2 : p - 1, as_ = left_dir ? p - 1 : p + 2;
+      n.Nh = (l2_flag && bs_ >= 0 && bs_ <= N - 1) ? c->norm_slot(nbeh, bs_) : nullptr;     // only "is there one": the values are in LDS
+      n.Ng = (l2_flag && as_ >= 0 && as_ <= N - 1) ? c->norm_slot(nahe, as_) : nullptr;
+      n.Nh_new = l2_flag ? c->norm_slot(nbeh, sb) : nullptr;
+    }
+    n.Bnew = c->Bnew;
+    n.out_behind = c->core_slot(sb);
+    // the label core is written once, by the last step: into the buffer the per-step sequence would have ended on
+    n.out_ahead = c->lab[(c->lab_cur + (n_steps - k)) & 1];
+    n.write_ahead = (k == n_steps - 1);
+    n.metrics = c->metrics + 2 * (size_t)k;
+    n.svd_stop2 = c->svd_stop2; n.chol_thr = c->chol_thr;
+    n.status = c->status; n.counters = c->counters;
+    n.pipe = 1; n.persist = 1; n.z_first = (k == 0);
+    ps.w = WidePipeParams{};
+    fill_wide_pipe(c, ps.w, left_dir, k, act_fn, loss_fn, T);
+    WidePipeParams &wp = ps.w;
+    n.zr = k == 0 ? 1 : wp.hprev * D;
+    if (n.zr > 64) return give_up();
+    n.z_rows = n.zr; n.zsize = n.zr * D * D * g * L;
+    n.zred = zr2[k & 1]; n.red = n.zred; n.Tsrc = c->Tbuf[k & 1];
+    n.zready = fl + 2; n.zwant = (unsigned)k + 1; n.tready = fl + 1; n.twant = (unsigned)k + 1;
+    n.flag = fl + 0; n.token = (unsigned)k + 1;
+    n.coreflag = fl + 3; n.coretoken = (unsigned)k + 1; n.abort_flag = fl + 4;
+    n.Mcap = Mcap;
+    lds_narrow = std::max(lds_narrow, nlds);
+    // ---- batch-side workgroups: f from B_new(k), pre-gradient of step k+1
+    wp.do_ext = k >= 1; wp.do_f = 1; wp.wait_flag = 1;
+    wp.do_z = (k + 1 <= N - 2);
+    wp.tiles_per_wg = tpw; wp.nwide = nwide; wp.ngroups = (nwide + kPipeGroupMax - 1) / kPipeGroupMax; wp.gsz = kPipeGroupMax;
+    wp.wg0 = 2; wp.persist = 1; wp.flag = fl + 0; wp.token = (unsigned)k + 1;
+    wp.coreflag = fl + 3; wp.corewant = (unsigned)k; wp.zready = fl + 2; wp.zpublish = (unsigned)k + 2; wp.abort_flag = fl + 4;
+    wp.zred = zr2[(k + 1) & 1];
+    wp.gcnt = c->pst_cnt + (size_t)k * 32; wp.tcnt = wp.gcnt + 16;
+    if (!wide_pipe_fits(c, wp)) return give_up();
+    if (wp.do_z && wp.nwide <= 256 && (size_t)16 * (wp.zsize + kMetricSlots) * sizeof(float) <= wide_pipe_lds_bytes(wp) - 16) { wp.gsz = wp.nwide; wp.ngroups = 1; wp.one_level = 1; }
+    lds_wide = std::max(lds_wide, wide_pipe_lds_bytes(wp));
+    // ---- helper workgroup: T_k
+    PersistHelperParams &t = ps.t;
+    t.zr = n.zr; t.s = s; t.g = g; t.L = L;
+    t.W = k == 0 ? nullptr : c->Bnew;
+    t.lab = n.lab; t.pl = n.pl;
+    t.T = c->Tbuf[k & 1];
+    t.flag = fl + 0; t.want = (unsigned)k; t.tready = fl + 1; t.publish = (unsigned)k + 1; t.abort_flag = fl + 4; t.status = c->status;
+    lds_help = std::max(lds_help, persist_helper_lds_bytes(t.zr, s, g, L));
+    if ((size_t)t.zr * D * D * g * L + kMetricSlots > (size_t)c->zstride) return give_up();
+    // ---- the bookkeeping of the per-step path
+    c->bond[p] = m;
+    c->l_pos = sa;
+    c->lab_cur ^= 1;
+    c->prev_h = h; c->prev_g = g; c->prev_p = p;
+    bytes += 4.0 * c->b * (2.0 * h + g + 3.0 * D + 2.0 * L + 1.0);
+    flops += 4.0 * c->b * D * D * h * g * L + 2.0 * c->b * D * h * h;
+    c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
+  }
+  const size_t lds = std::max(std::max(lds_narrow + pbytes, lds_wide), lds_help);
+  if (lds > 160 * 1024) return give_up();
+  const int persist_off = (int)((lds - pbytes) & ~(size_t)15);
+  for (int k = 0; k < n_steps; ++k) st[k].n.persist_off = persist_off;
+  // ---- enqueue: records, zeroed flags and counters, one launch
+  HIP_TRY(hipMemcpyAsync(c->pst_dev, st, (size_t)n_steps * sizeof(PersistStep), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->pro_dev, &pro, sizeof(WidePipeParams), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->pst_ev[buf], c->stream));
+  c->pst_cur ^= 1;
+  HIP_TRY(hipMemsetAsync(c->pst_flags, 0, 8 * sizeof(unsigned), c->stream));
+  HIP_TRY(hipMemsetAsync(c->pst_cnt, 0, (size_t)(n_steps + 1) * 32 * sizeof(unsigned), c->stream));
+  launch_sweep_persist(c->pst_dev, c->pro_dev, n_steps, 2 + nwide, lds, c->stream);
+  HIP_TRY(hipGetLastError());
+  c->prev_left_dir = left_dir;
+  c->cnt_steps += n_steps; c->cnt_bytes += bytes; c->cnt_flops += flops;
+  c->sweep_launches += 1; c->step_launches += n_steps; c->persist_sweeps += 1;
+  c->Bnew_valid = true; c->f_current = true; c->Z_valid = false;
+  return 1;
+}
+
 // mode 0: n_steps full steps.  mode 1 (standalone update_B): ONE step up to and including the update of
 // the merged tensor -- the behind environment is extended and B_new lands in the debug block, but no
 // SVD runs and cores, bonds and l_pos stay as they are.  Bdirect_dev: merged tensor to use instead of
@@ -904,7 +1086,12 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     c->sweep_ev_used += 2;
   }
 
-  for (int step = 0; step < n_steps; ++step) {
+  int done_persist = 0;
+  if (mode == 0 && !Bdirect_dev && first_of_sweep) {
+    done_persist = sweep_persist(c, left_dir, n_steps, lr, weight_dec, l2_flag, act_fn, loss_fn, T, trunc_policy);
+    if (done_persist < 0) return done_persist;
+  }
+  for (int step = 0; step < (done_persist ? 0 : n_steps); ++step) {
     const int l = c->l_pos;
     const int p = left_dir ? l - 1 : l;
     const int k = left_dir ? (N - 2 - p) : p;
@@ -1361,6 +1548,12 @@ extern "C" int tnml_set_step_pipeline(tnml_ctx *c, int on) {
   c->pipe_enabled = on != 0;
   c->pipe_tiles = on >= 2 ? on : (on == 1 ? 2 : 1);
   c->Z_valid = false;
+  return TNML_OK;
+}
+
+extern "C" int tnml_set_persistent(tnml_ctx *c, int on) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  c->persist_enabled = on != 0;
   return TNML_OK;
 }
 

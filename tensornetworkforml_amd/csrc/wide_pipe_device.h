@@ -77,10 +77,30 @@ struct WidePipeParams {
   const unsigned *flag;  // set to `token` by the narrow workgroup once B_new(j) is stored
   unsigned token;
   int *status;
+  // persistent sweep (sweep_persist_kernel): the workgroup loops over the steps; producers and consumers of the same launch
+  int persist;
+  const unsigned *coreflag;   // >= corewant: the extension core A_{j-1} is stored (agent scope) -- read with agent-scope loads
+  unsigned corewant;
+  unsigned *zready;           // set to zpublish once the reduced pre-gradient is stored (agent scope)
+  unsigned zpublish;
+  unsigned *abort_flag;
 };
 
+// Bounded wait of ONE lane until *flag >= want (flags of a persistent sweep only grow).  0: seen, 1: timed out, 2: another workgroup
+// gave up first (abort word set).  Relaxed agent-scope polls; the caller meets its workgroup at a barrier before any load of the
+// handed-off data.
+__device__ inline int spin_wait_ge(const unsigned *flag, unsigned want, const unsigned *abort_flag) {
+  for (int spins = 0; spins < (1 << 22); ++spins) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return 0;
+    if ((spins & 63) == 63 && abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 2;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return 1;
+}
+
 struct WidePipeDims { int nI, IP, JP, RS, KA, HS, I3, J3, EH; };
-__host__ __device__ inline WidePipeDims wide_pipe_dims(const WidePipeParams &p) {
+template <class WP>
+__host__ __device__ inline WidePipeDims wide_pipe_dims(const WP &p) {
   WidePipeDims d;
   d.nI = p.first ? 1 : p.hj * kD;            // rows i = (h_j, d_j) of B_new(j) and of P'
   d.IP = upm(d.nI, 16);
@@ -95,7 +115,8 @@ __host__ __device__ inline WidePipeDims wide_pipe_dims(const WidePipeParams &p) 
 }
 
 struct WidePipeSmem { float *sX, *sF, *sGl, *sPpp, *sA, *sE, *sPp, *sQp, *sBp, *sPg, *sQn, *sFp, *sMet; size_t floats; };
-__host__ __device__ inline WidePipeSmem wide_pipe_carve(float *base, const WidePipeParams &p, const WidePipeDims &d) {
+template <class WP>
+__host__ __device__ inline WidePipeSmem wide_pipe_carve(float *base, const WP &p, const WidePipeDims &d) {
   WidePipeSmem w;
   float *q = base;
   w.sX = q; q += 4 * kTS * kD;                                  // features of sites j-1, j, j+1, j+2
@@ -124,16 +145,38 @@ inline int wide_pipe_ztiles(const WidePipeParams &p) {
   const WidePipeDims d = wide_pipe_dims(p);
   return p.L * (d.I3 / 16) * (d.J3 / 16);
 }
-struct NarrowParams;
 // grid = w.wg0 + w.nwide workgroups of 1024 threads (kernels_narrow.hip)
 void launch_step_pipe(const NarrowParams &p, const WidePipeParams &w, size_t lds_bytes, hipStream_t st);
+
+// persistent sweep (kernels_narrow.hip: sweep_persist_kernel): what the helper workgroup needs for T_k, and one record per step
+struct PersistHelperParams {
+  int zr, s, g, L;           // T_k[zr][D][D][g][L] = sum_s W[zr][D][s][L] . A_{k+1}(s, d', g)
+  const float *W;            // B_new(k-1) (contiguous), or nullptr at k == 0: the label core `lab` is W
+  CoreView lab, pl;
+  float *T;
+  const unsigned *flag;      // >= want: B_new(k-1) is stored (want == 0: nothing to wait for)
+  unsigned want;
+  unsigned *tready;          // set to `publish` once T_k is stored
+  unsigned publish;
+  unsigned *abort_flag;
+  int *status;
+};
+struct PersistStep { NarrowParams n; WidePipeParams w; PersistHelperParams t; };
+inline size_t persist_helper_lds_bytes(int zr, int s, int g, int L) {
+  const size_t nW = (size_t)zr * kD * s * L, nP = (size_t)s * kD * g, nT = (size_t)zr * kD * kD * g * L;
+  return (((nW + 3) & ~(size_t)3) + ((nP + 3) & ~(size_t)3) + nT) * sizeof(float) + 32;
+}
+void launch_sweep_persist(const PersistStep *steps_dev, const WidePipeParams *pro_dev, int n_steps, int grid, size_t lds_bytes,
+                          hipStream_t st);
 
 
 // ------------------------------------------------------------------------------------------------------------------
 // One batch-side workgroup (1024 threads, 16 waves).  MFMA lane maps (v_mfma_f32_16x16x4_f32): A[row = lane & 15]
 // [k = lane >> 4], B[k = lane >> 4][col = lane & 15], C/D col = lane & 15, row = 4 (lane >> 4) + reg.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
+// returns true when the workgroup gave up (persistent sweep: a wait timed out here or elsewhere)
+template <class WP>
+__device__ inline bool wide_pipe_block(const WP &p, float *smem) {
   const WidePipeDims dm = wide_pipe_dims(p);
   const WidePipeSmem w = wide_pipe_carve(smem, p, dm);
   const int tid = threadIdx.x, NT = kPipeThreads;
@@ -153,6 +196,17 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
   float met[4] = {0.f, 0.f, 0.f, 0.f};      // thread 0..3: running metric sums of this workgroup
 
   bool flag_seen = !p.wait_flag;
+  __shared__ int sGiveUp;
+  if (p.persist) {
+    // the extension core A_{j-1} is written by the update workgroup of THIS launch (end of its step j-1)
+    if (tid == 0) {
+      const int bad = p.do_ext ? spin_wait_ge(p.coreflag, p.corewant, p.abort_flag) : 0;
+      if (bad == 1) { atomicOr(p.status, 8); __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      sGiveUp = bad;
+    }
+    lds_barrier();
+    if (sGiveUp) return true;
+  }
   for (int tt = 0; tt < p.tiles_per_wg; ++tt) {
     const int tile = wg + tt * p.nwide;
     if (tile >= p.ntiles) break;            // block-uniform
@@ -170,7 +224,10 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
       for (int e = tid; e < dm.KA * dm.HS; e += NT) {             // A[i''][hn], zero padded
         const int o = e % dm.HS, i = e / dm.HS;
         float v = 0.f;
-        if (i < hprev * kD && o < hj) v = p.ext_core.base[(i >> 1) * p.ext_core.s_in + (i & 1) * p.ext_core.s_d + o * p.ext_core.s_out];
+        if (i < hprev * kD && o < hj) {
+          const float *src = p.ext_core.base + ((i >> 1) * p.ext_core.s_in + (i & 1) * p.ext_core.s_d + o * p.ext_core.s_out);
+          v = p.persist ? ld_sc1(src) : *src;
+        }
         w.sA[e] = v;
       }
     } else {
@@ -236,16 +293,23 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
     if (p.do_f) {
       if (!flag_seen) {
         if (tid == 0) {
-          int spins = 0;
-          while (__hip_atomic_load(p.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.token && spins < (1 << 21)) {
-            __builtin_amdgcn_s_sleep(16);
-            ++spins;
+          if (p.persist) {
+            const int bad = spin_wait_ge(p.flag, p.token, p.abort_flag);
+            if (bad == 1) { atomicOr(p.status, 8); __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            sGiveUp = bad;
+          } else {
+            int spins = 0;
+            while (__hip_atomic_load(p.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.token && spins < (1 << 21)) {
+              __builtin_amdgcn_s_sleep(16);
+              ++spins;
+            }
+            if (spins >= (1 << 21)) atomicOr(p.status, 8);
           }
-          if (spins >= (1 << 21)) atomicOr(p.status, 8);
         }
         flag_seen = true;
       }
       lds_barrier();                                            // the poll is over; P', Q', Qn are complete
+      if (p.persist && sGiveUp) return true;
       const int rowlen = nJ * L;
       if (tt == 0) {                                              // B'[i][(jj, l)] at the odd row stride, zero padded
         if (p.wait_flag && (rowlen & 3) == 0) {
@@ -354,7 +418,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
       }
     }
   }
-  if (!p.do_z) return;
+  if (!p.do_z) return false;
 
   // ---- partial tensor of this workgroup -> slab (agent-scope stores), then the two-level fixed-order reduction ----------
   float *slab = p.slabs + (size_t)wg * p.slab_stride;
@@ -394,7 +458,7 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
   const int g_lo = grp * p.gsz, g_n = min(p.gsz, p.nwide - g_lo);
   if (tid == 0) sTicket = __hip_atomic_fetch_add(p.gcnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   lds_barrier();
-  if (sTicket != (unsigned)(g_n - 1)) return;                     // not the last arriver of its group
+  if (sTicket != (unsigned)(g_n - 1)) return false;               // not the last arriver of its group
   // The last arriver reads what the other workgroups stored: one agent-scope acquire (invalidates this CU's L1 and the
   // non-coherent lines of its L2), drained, then a barrier, then ordinary 16-byte loads, all of an element's summands
   // in flight together (a group has at most kPipeGroupMax members).
@@ -404,6 +468,14 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     lds_barrier();
+  };
+  // persistent sweep: the reduced tensor is read by the update workgroup of the same launch -- agent-scope stores, drained, then
+  // the ready flag
+  auto publish_zred = [&]() {
+    if (!p.persist) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (tid == 0) __hip_atomic_store(p.zready, p.zpublish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto sum_slabs = [&](const float *src, int count, float *dst, bool publish) {
     const int n4 = (n + 3) / 4;
@@ -448,10 +520,16 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
       float4 a = part[e];
 #pragma unroll
       for (int c = 1; c < 16; ++c) { const float4 b = part[c * n4 + e]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-      *reinterpret_cast<float4 *>(p.zred + 4 * e) = a;
+      if (p.persist) {
+        tn_uvec4 o; o.x = __float_as_uint(a.x); o.y = __float_as_uint(a.y); o.z = __float_as_uint(a.z); o.w = __float_as_uint(a.w);
+        st_sc1_b128(sc1_rsrc(p.zred), (unsigned)(16 * e), o);
+      } else {
+        *reinterpret_cast<float4 *>(p.zred + 4 * e) = a;
+      }
     }
     if (tid == 0) __hip_atomic_store(p.gcnt + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    return;
+    publish_zred();
+    return false;
   }
   // level 1: the group's slabs in slab order
   acquire_all();
@@ -461,12 +539,14 @@ __device__ inline void wide_pipe_block(const WidePipeParams &p, float *smem) {
   lds_barrier();
   if (tid == 0) sTicket = __hip_atomic_fetch_add(p.tcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   lds_barrier();
-  if (sTicket != (unsigned)(p.ngroups - 1)) return;               // not the last group
+  if (sTicket != (unsigned)(p.ngroups - 1)) return false;         // not the last group
   // level 2: the group sums in group order -> the reduced tensor the next launch reads (ordinary stores: the kernel
   // boundary publishes them)
   acquire_all();
-  sum_slabs(p.gslabs, p.ngroups, p.zred, false);
+  sum_slabs(p.gslabs, p.ngroups, p.zred, p.persist != 0);
   if (tid == 0) __hip_atomic_store(p.tcnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  publish_zred();
+  return false;
 }
 
 }  // namespace tnml

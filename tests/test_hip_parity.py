@@ -403,6 +403,7 @@ def test_counters_and_classic_sequence_agree_with_the_pipelined_step():
     outs = []
     for pipe in (True, False):
         ctx = make_ctx(N, D, L, M, gu.indexed(d, 'init_core', N), 0, d['X'], d['y'])
+        ctx.set_persistent(False)            # one launch per step (the persistent sweep has its own test below)
         ctx.set_step_pipeline(pipe)
         ctx.profile_reset()
         ctx.forward()
@@ -416,3 +417,59 @@ def test_counters_and_classic_sequence_agree_with_the_pipelined_step():
         ctx.close()
     assert relerr(outs[0][1], outs[1][1]) < 1e-4
     assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-5
+
+
+@pytest.mark.parametrize('policy,M,N,b,L', [('fixed', 20, 48, 300, 2), ('reference', 10, 40, 130, 2), ('fixed', 12, 25, 77, 3),
+                                            ('fixed', 8, 33, 64, 2), ('reference', 3, 14, 9, 2)])
+def test_persistent_sweep_matches_per_step_launches_and_oracle(policy, M, N, b, L):
+    """A full sweep as ONE persistent launch (default) against the same sweep as one launch per step and against the float64
+    oracle: f, per-step metrics, bonds, and the network function afterwards; three sweeps, both directions, ragged batches,
+    chains of odd and even length (the label core ends in either of its two buffers)."""
+    rng = np.random.default_rng(11)
+    D = 2
+    p = rng.random((b, N)) * (rng.random((b, N)) > 0.6)
+    X = np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32)
+    y = rng.integers(0, L, b)
+    cores = mo.random_cores(N, M, D, L, rng=rng, scale=M * 0.5 * 0.64 * D)
+    st = mo.MPSState(N, D, L, M, cores)
+    mo.calibrate(st, X.astype(np.float64))
+    cores32 = [c.astype(np.float32) for c in st.cores]
+    st = mo.MPSState(N, D, L, M, [c.astype(np.float64) for c in cores32])
+    kw = dict(lr=1e-2, weight_dec=1e-3, L2_flag=True, act_fn='softmax', loss_fn='full_cross_ent', T=0.1, trunc=policy)
+    ctxs = []
+    for persistent in (True, False):
+        ctx = make_ctx(N, D, L, M, cores32, 0, X, y)
+        ctx.set_persistent(persistent)
+        ctx.profile_reset()
+        ctxs.append(ctx)
+    X64 = X.astype(np.float64)
+    for sw in range(3):
+        f_o = mo.forward(st, X64)
+        left_dir = st.l_pos == N - 1
+        vh = [[], []]
+        f_o = mo.sweep(st, X64, y, f_o, kw['lr'], kw['weight_dec'], L2_flag=True, left_dir=left_dir, var_hist=vh,
+                       act_fn=kw['act_fn'], loss_fn=kw['loss_fn'], T=kw['T'], trunc=policy)
+        res = []
+        for ctx in ctxs:
+            ctx.forward()
+            met, f_d = ctx.sweep(left_dir, N - 1, True, kw['lr'], kw['weight_dec'], True, kw['act_fn'], kw['loss_fn'], kw['T'], policy)
+            res.append((met, f_d))
+            assert relerr(f_d, f_o) < 5e-3, sw
+            assert np.abs(met[:, 0] - np.array(vh[0])).max() <= 2.0 / b + 1e-6
+            assert np.abs(met[:, 1] - np.array(vh[1])).max() < 2e-3
+            _, bond_d, lp = ctx.get_cores()
+            assert list(bond_d) == list(st.bond) and lp == st.l_pos
+        # the two device paths: the same sums in another association order
+        assert relerr(res[0][1], res[1][1]) < 2e-4, sw
+        assert np.abs(res[0][0][:, 0] - res[1][0][:, 0]).max() <= 1.0 / b + 1e-6
+        assert np.abs(res[0][0][:, 1] - res[1][0][:, 1]).max() < 2e-4
+    # the persistent context made one launch per sweep, the other one N - 1 (+ the launch that starts a sweep)
+    assert ctxs[0].counters()['launches'] == 3 and ctxs[0].counters()['sweep_steps'] == 3 * (N - 1)
+    assert ctxs[1].counters()['launches'] >= 3 * (N - 1)
+    p2 = rng.random((b, N))
+    X2 = np.stack([np.sin(np.pi * p2 / 2), np.cos(np.pi * p2 / 2)], -1).astype(np.float32)
+    f2 = mo.forward(st, X2.astype(np.float64))
+    for ctx in ctxs:
+        ctx.set_input(X2, y)
+        assert relerr(ctx.forward(), f2) < 5e-3
+        ctx.close()
