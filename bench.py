@@ -150,6 +150,7 @@ def main():
     ap.add_argument('--no-cold', action='store_true', help='skip the re-initialised (cold start) passes')
     ap.add_argument('--no-resident', action='store_true', help='skip the secondary single-resident-batch measurement')
     ap.add_argument('--classic', action='store_true', help='classic launch sequence instead of the pipelined single-launch step')
+    ap.add_argument('--per-step', action='store_true', help='one launch per sweep step (round 2) instead of the persistent per-sweep launch')
     ap.add_argument('--pipe-tiles', type=int, default=0, help='sample tiles per batch-side workgroup on steps with a long SVD (tnml_set_step_pipeline(ctx, n), n >= 2)')
     ap.add_argument('--sync-interval', type=int, default=0, help='drain the stream every so many sweep steps (runs under rocprofv3 --pmc)')
     ap.add_argument('--check-launches', action='store_true', help='read the launch status back after every kernel launch')
@@ -178,6 +179,8 @@ def main():
         ctx.set_sync_interval(args.sync_interval)
     if args.check_launches:
         ctx.debug_enable(4)
+    if args.per_step:
+        ctx.set_persistent(False)
     if args.classic:
         ctx.set_step_pipeline(False)
     elif args.pipe_tiles >= 2:
@@ -336,10 +339,14 @@ def main():
                            'algorithmic_flops_per_step': fl, 'algorithmic_bytes_per_step': bstep, 'step_avg_us_hip_events': step_us}
     else:
         ach = bstep / (step_us * 1e-6) / 1e9
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'step_pipe_kernel' if all_pipe else 'wide_step_mfma_kernel + narrow_step_kernel',
+        persistent = all_pipe and main_run['launches'] <= 2 * args.steps
+        out['roofline'] = {'bound': 'hbm', 'kernel': ('sweep_persist_kernel (ONE launch per sweep of %d steps; the figures are per step)' % (N - 1)) if persistent
+                           else ('step_pipe_kernel' if all_pipe else 'wide_step_mfma_kernel + narrow_step_kernel'),
                            'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
-                           'algorithmic_bytes_per_launch': bstep, 'kernel_avg_us_hip_events': step_us, 'launches_timed': step_launches,
-                           'note': 'one launch = one whole sweep step; the step is bound by the sequential SVD of its merged tensor '
+                           'algorithmic_bytes_per_launch': bstep * ((N - 1) if persistent else 1), 'algorithmic_bytes_per_step': bstep,
+                           'kernel_avg_us_hip_events': step_us * ((N - 1) if persistent else 1), 'step_avg_us_hip_events': step_us,
+                           'launches_timed': main_run['launches'] if persistent else step_launches, 'steps_timed': step_launches,
+                           'note': 'one launch = one whole sweep (persistent kernel) or one whole sweep step; the step is bound by the sequential SVD of its merged tensor '
                                    '(critical_path below), not by HBM'}
         pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_%s.json' % args.config)
         if os.path.exists(pmc) and args.policy == 'fixed' and not args.no_l2 and not args.classic:
