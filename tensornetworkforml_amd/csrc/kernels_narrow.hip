@@ -234,17 +234,16 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
     for (int item = wave_u; item < 2 * ncol; item += NT >> 6) {
       const bool isT = item >= ncol;
       const int ct = isT ? item - ncol : item;
-      const float *S = isT ? p.Tsrc : p.zred;
-      const int col = min(ct * 16 + rr, RW - 1);
-      float bv[kMaxK];
+      const int col = min(ct * 16 + rr, RW - 1), j = ct * 16 + rr;
+      if (!isT) {                                 // raw gradient: float32 operands, float32 matrix pipe (as the per-step path)
+        float bv[kMaxK];
 #pragma unroll
-      for (int ks = 0; ks < kMaxK; ++ks) {
-        const int row = 4 * ks + qq;
-        bv[ks] = (ks < nk && row < zr) ? ld_sc1(S + (size_t)row * RW + col) : 0.f;
-      }
-      for (int ti = 0; ti < tmh; ++ti) {
-        const int hh = min(ti * 16 + rr, h - 1);
-        if (!isT) {
+        for (int ks = 0; ks < kMaxK; ++ks) {
+          const int row = 4 * ks + qq;
+          bv[ks] = (ks < nk && row < zr) ? ld_sc1(p.zred + (size_t)row * RW + col) : 0.f;
+        }
+        for (int ti = 0; ti < tmh; ++ti) {
+          const int hh = min(ti * 16 + rr, h - 1);
           fvec4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < kMaxK; ++ks) {
@@ -253,22 +252,29 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
             const float a = row < zr ? PL.A[row * h + hh] : 0.f;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[ks], acc, 0, 0, 0);
           }
-          const int j = ct * 16 + rr;
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int i = ti * 16 + 4 * qq + reg;
             if (i < h && j < RW) sRaw[i * RW + j] = acc[reg];
           }
-        } else {
+        }
+      } else {                                    // merged tensor: float64 throughout (see PersistLds::Ad)
+        double bv[kMaxK];
+#pragma unroll
+        for (int ks = 0; ks < kMaxK; ++ks) {
+          const int row = 4 * ks + qq;
+          bv[ks] = (ks < nk && row < zr) ? __hip_atomic_load(p.Tsrc + (size_t)row * RW + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+        for (int ti = 0; ti < tmh; ++ti) {
+          const int hh = min(ti * 16 + rr, h - 1);
           dvec4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int ks = 0; ks < kMaxK; ++ks) {
             if (ks >= nk) break;
             const int row = 4 * ks + qq;
-            const double a = row < zr ? (double)PL.A[row * h + hh] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (double)bv[ks], acc, 0, 0, 0);
+            const double a = row < zr ? PL.Ad[row * h + hh] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[ks], acc, 0, 0, 0);
           }
-          const int j = ct * 16 + rr;
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int i = ti * 16 + qq + 4 * reg;
@@ -1058,6 +1064,7 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
     k.dVs[kk * mk + sp] = vq * k.dSq[ne + sp];
     if (short_rows) {                       // kk = row index i = h_*D + dk  -> behind core
       k.sCb[kk * mk + sp] = v;
+      if (p.persist) PL.Ad[kk * mk + sp] = vq * k.dSq[sp];
       st_behind((kk / D) * ob_s_h + (kk % D) * ob_s_d + sp * p.ob_s_m, v);
     } else {                                // kk = column index (dk1*g + g_)*L + l -> ahead core
       const int l = kk % L, q = kk / L;
@@ -1089,6 +1096,7 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
            [&](int dk, int h_, int sp, double acc) {
              const float v = (float)acc;
              k.sCb[__mul24(h_ * D + dk, mk) + sp] = v;
+             if (p.persist) PL.Ad[__mul24(h_ * D + dk, mk) + sp] = acc;
              st_behind(__mul24(h_, ob_s_h) + dk * ob_s_d + __mul24(sp, p.ob_s_m), v);
            });
   }
@@ -1187,7 +1195,7 @@ __device__ inline bool persist_helper_block(const HP &t, unsigned char *smem_raw
   float *sW = (float *)smem_raw;                           // [zr D][s][L]   rows (i, d) of W_{k-1}
   const int nW = zr * D * s * L, nP = s * D * g, nT = zr * D * D * g * L;
   float *sP = sW + ((nW + 3) & ~3);                        // [s][D g]       A_{k+1}(s, (d', g))
-  float *oT = sP + ((nP + 3) & ~3);                        // [zr D][D g][L] the result, staged for 16-byte stores
+  double *oT = (double *)(sP + ((nP + 3) & ~3));           // [zr D][D g][L] the result (float64), staged for 16-byte stores
   __shared__ int sBad;
   if (tid == 0) {
     const int bad = t.want ? spin_wait_ge(t.flag, t.want, t.abort_flag) : 0;
@@ -1216,13 +1224,13 @@ __device__ inline bool persist_helper_block(const HP &t, unsigned char *smem_raw
   lds_barrier();
   const int DG = D * g;
   mm_lds(L, zr * D, DG, s, sW, 1, s * L, L, sP, 0, DG, 1,
-         [&](int l, int row, int col, double v) { oT[(row * DG + col) * L + l] = (float)v; });
+         [&](int l, int row, int col, double v) { oT[(row * DG + col) * L + l] = v; });
   lds_barrier();
-  if ((nT & 3) == 0) {
+  if ((nT & 1) == 0) {
     const __amdgpu_buffer_rsrc_t rT = sc1_rsrc(t.T);
-    for (int e = 4 * tid; e < nT; e += 4 * NT) st_sc1_b128(rT, (unsigned)e * 4u, *reinterpret_cast<const tn_uvec4 *>(oT + e));
+    for (int e = 2 * tid; e < nT; e += 2 * NT) st_sc1_b128(rT, (unsigned)e * 8u, *reinterpret_cast<const tn_uvec4 *>(oT + e));
   } else {
-    for (int e = tid; e < nT; e += NT) st_sc1(t.T + e, oT[e]);
+    for (int e = tid; e < nT; e += NT) __hip_atomic_store(t.T + e, oT[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
@@ -1241,7 +1249,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sweep_persist_kernel(const Per
   const int blk = blockIdx.x;
   if (blk == 0) {
     const PersistLds PL = persist_lds(smem_raw + steps[0].n.persist_off, steps[0].n.Mcap);
-    if (threadIdx.x == 0) { PL.A[0] = 1.f; PL.invs[0] = 1.0; PL.Nh[0] = 1.0; }     // step 0 projects with the identity
+    if (threadIdx.x == 0) { PL.A[0] = 1.f; PL.Ad[0] = 1.0; PL.invs[0] = 1.0; PL.Nh[0] = 1.0; }     // step 0 projects with the identity
     lds_barrier();
 #pragma nounroll
     for (int k = 0; k < n_steps; ++k)

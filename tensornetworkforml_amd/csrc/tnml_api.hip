@@ -119,7 +119,8 @@ struct tnml_ctx {
   WidePipeParams *pro_dev = nullptr, *pro_host[2] = {nullptr, nullptr};
   hipEvent_t pst_ev[2] = {nullptr, nullptr};
   int pst_cur = 0;
-  float *zred2 = nullptr, *Tbuf[2] = {nullptr, nullptr};
+  float *zred2 = nullptr;
+  double *Tbuf[2] = {nullptr, nullptr};
   unsigned *pst_cnt = nullptr, *pst_flags = nullptr;
   long long persist_sweeps = 0;
   int num_cus = 256;
@@ -241,8 +242,8 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipMalloc(&c->pipe_cnt, 32 * sizeof(unsigned)));
   HIP_TRY(hipMemset(c->pipe_cnt, 0, 32 * sizeof(unsigned)));
   HIP_TRY(hipMalloc(&c->zred2, (size_t)c->zstride * sizeof(float)));
-  HIP_TRY(hipMalloc(&c->Tbuf[0], (size_t)c->zstride * sizeof(float)));
-  HIP_TRY(hipMalloc(&c->Tbuf[1], (size_t)c->zstride * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->Tbuf[0], (size_t)c->zstride * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->Tbuf[1], (size_t)c->zstride * sizeof(double)));
   HIP_TRY(hipMalloc(&c->pst_dev, (size_t)N * sizeof(PersistStep)));
   HIP_TRY(hipMalloc(&c->pro_dev, sizeof(WidePipeParams)));
   for (int i = 0; i < 2; ++i) {

@@ -124,7 +124,7 @@ struct NarrowParams {
   int write_ahead;         // the new label core is wanted (last step of the launch); otherwise its product is skipped
   int persist_off;         // byte offset of the persistent LDS region (PersistLds), Mcap its capacity per bond
   int Mcap;
-  const float *Tsrc;       // T_k[zr][D][D][g][L], written by the helper workgroup of this launch
+  const double *Tsrc;      // T_k[zr][D][D][g][L] (float64: exact sums of float32 products), written by the helper workgroup of this launch
   const unsigned *zready;  // >= zwant: Z_k (zred) is complete;  tready >= twant: T_k is complete
   const unsigned *tready;
   unsigned zwant, twant;
@@ -134,16 +134,19 @@ struct NarrowParams {
 };
 
 // LDS that survives from one step of a persistent sweep to the next (update workgroup only)
-struct PersistLds { double *Nh, *invs; float *A; };
+struct PersistLds { double *Nh, *invs, *Ad; float *A; };
 __host__ __device__ inline PersistLds persist_lds(unsigned char *base, int Mcap) {
   PersistLds q;
   q.Nh = (double *)base;                       // [m][m]   behind norm environment of the next step
   q.invs = q.Nh + (size_t)Mcap * Mcap;         // [m]      1 / sigma of the kept columns
-  q.A = (float *)(q.invs + ((Mcap + 1) & ~1)); // [D h][m] behind core of the step just finished (U sqrt(S))
+  q.Ad = q.invs + ((Mcap + 1) & ~1);           // [D h][m] behind core of the step just finished (U sqrt(S)) before its rounding to float32:
+                                               //          the projection of T with it divides by sigma, so rounding errors of A' or T
+                                               //          would come back multiplied by sigma_max / sigma_j
+  q.A = (float *)(q.Ad + (size_t)kD * Mcap * Mcap);   // the same as stored (float32): projects the float32 pre-gradient Z
   return q;
 }
 inline size_t persist_lds_bytes(int Mcap) {
-  return ((size_t)Mcap * Mcap + ((Mcap + 1) & ~1)) * sizeof(double) + (size_t)kD * Mcap * Mcap * sizeof(float) + 16;
+  return ((size_t)Mcap * Mcap + ((Mcap + 1) & ~1) + (size_t)kD * Mcap * Mcap) * sizeof(double) + (size_t)kD * Mcap * Mcap * sizeof(float) + 16;
 }
 
 struct NormChainSite {

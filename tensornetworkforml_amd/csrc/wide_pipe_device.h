@@ -153,7 +153,7 @@ struct PersistHelperParams {
   int zr, s, g, L;           // T_k[zr][D][D][g][L] = sum_s W[zr][D][s][L] . A_{k+1}(s, d', g)
   const float *W;            // B_new(k-1) (contiguous), or nullptr at k == 0: the label core `lab` is W
   CoreView lab, pl;
-  float *T;
+  double *T;                 // float64: exact sums of float32 products
   const unsigned *flag;      // >= want: B_new(k-1) is stored (want == 0: nothing to wait for)
   unsigned want;
   unsigned *tready;          // set to `publish` once T_k is stored
@@ -164,7 +164,7 @@ struct PersistHelperParams {
 struct PersistStep { NarrowParams n; WidePipeParams w; PersistHelperParams t; };
 inline size_t persist_helper_lds_bytes(int zr, int s, int g, int L) {
   const size_t nW = (size_t)zr * kD * s * L, nP = (size_t)s * kD * g, nT = (size_t)zr * kD * kD * g * L;
-  return (((nW + 3) & ~(size_t)3) + ((nP + 3) & ~(size_t)3) + nT) * sizeof(float) + 32;
+  return (((nW + 3) & ~(size_t)3) + ((nP + 3) & ~(size_t)3)) * sizeof(float) + nT * sizeof(double) + 32;
 }
 void launch_sweep_persist(const PersistStep *steps_dev, const WidePipeParams *pro_dev, int n_steps, int grid, size_t lds_bytes,
                           hipStream_t st);
