@@ -217,17 +217,44 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
   float *sRaw = k.fBp;                          // raw gradient [h][RW] (float): dead before phase 5 rewrites fBp
   if (p.persist) {
     if (tid == 0) {
-      int bad = spin_wait_ge(p.zready, p.zwant, p.abort_flag);
-      if (!bad) bad = spin_wait_ge(p.tready, p.twant, p.abort_flag);
+      int bad = spin_wait_ge2(p.zready, p.zwant, p.tready, p.twant, p.abort_flag);
       if (bad == 1) { atomicOr(p.status, 4); __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       k.sFlag[3] = bad;
     }
     lds_barrier();
     if (k.sFlag[3]) return true;
+    if (p.stamps && tid == 0) p.stamps[20] = (double)(__builtin_amdgcn_s_memtime() - t_c0);      // flags seen
     if (tid < kMetricSlots) k.sTail[tid] = ld_sc1(p.zred + p.zsize + tid);
     for (int e = tid; e < h * h; e += NT) k.dNh[e] = p.Nh ? PL.Nh[e] : 1.0;
     for (int e = tid; e < g * g; e += NT) k.dNg[e] = p.Ng ? p.Ng[e] : 1.0;
     const int zr = p.zr, RW = RWz;
+    if (p.stage_lds) {
+      // Both operands through LDS (the launcher checked the room: Z_k over the region of the padded matrix copy and the two
+      // cores, T_k over the Jacobi buffers, all dead here; the raw gradient goes to its own area): ONE round trip of 16-byte
+      // agent-scope loads, then the two products on LDS operands, tiles dealt over all waves.
+      sRaw = reinterpret_cast<float *>(smem_raw + p.raw_off);
+      float *sZs = k.fBp;
+      double *sTs = k.Z;
+      const int nz4 = (zr * RW) >> 2, nt2 = (zr * RW) >> 1;
+      const __amdgpu_buffer_rsrc_t rZ = sc1_rsrc(p.zred), rT = sc1_rsrc(p.Tsrc);
+      tn_uvec4 qz[2], qt[4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { const int e = tid + u * NT; if (e < nz4) qz[u] = ld_sc1_b128(rZ, (unsigned)e * 16u); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = tid + u * NT; if (e < nt2) qt[u] = ld_sc1_b128(rT, (unsigned)e * 16u); }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { const int e = tid + u * NT; if (e < nz4) *reinterpret_cast<tn_uvec4 *>(sZs + 4 * e) = qz[u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = tid + u * NT; if (e < nt2) *reinterpret_cast<tn_uvec4 *>(sTs + 2 * e) = qt[u]; }
+      for (int e = tid + 2 * NT; e < nz4; e += NT) *reinterpret_cast<tn_uvec4 *>(sZs + 4 * e) = ld_sc1_b128(rZ, (unsigned)e * 16u);
+      for (int e = tid + 4 * NT; e < nt2; e += NT) *reinterpret_cast<tn_uvec4 *>(sTs + 2 * e) = ld_sc1_b128(rT, (unsigned)e * 16u);
+      lds_barrier();
+      if (p.stamps && tid == 0) p.stamps[21] = (double)(__builtin_amdgcn_s_memtime() - t_c0);    // operands in LDS
+      mm_lds_f32(h, RW, zr, PL.A, 1, h, sZs, RW, 1, [&](int i, int j, float v) { sRaw[i * RW + j] = v; });
+      const int tiles32 = ((h + 15) >> 4) * ((RW + 15) >> 4);
+      mm_lds(1, h, RW, zr, PL.Ad, 0, 1, h, sTs, 0, RW, 1,
+             [&](int, int i, int j, double v) { k.fB[i * RW + j] = (float)(v * PL.invs[i]); }, false, tiles32 & ((NT >> 6) - 1));
+    } else {
     const int lane = tid & 63, rr = lane & 15, qq = lane >> 4;
     const int ncol = (RW + 15) >> 4, nk = (zr + 3) >> 2, tmh = (h + 15) >> 4;
     constexpr int kMaxK = 16;                    // zr <= 64 (launcher)
@@ -282,6 +309,7 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
           }
         }
       }
+    }
     }
   }
   float *sZ = k.fBp, *sZc = sZ + (size_t)p.z_rows * RWz;
@@ -443,16 +471,11 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
   // ---- phases 2-3: weight decay term ------------------------------------------------------------
   if (p.l2_flag && !p.fused && !p.prep_ready) {
     // T = Nh^T . B over the behind bond:  T[e_, rest] = sum_a Nh[a, e_] B[a, rest]
-    small_gemm_f64(1, h, RW, h,
-                   [&](int, int i, int kk) { return k.dNh[kk * h + i]; },
-                   [&](int, int kk, int j) { return (double)k.fB[kk * RW + j]; },
-                   [&](int, int i, int j, double v) { k.dT[i * RW + j] = v; });
+    mm_lds(1, h, RW, h, k.dNh, 0, 1, h, k.fB, 0, RW, 1, [&](int, int i, int j, double v) { k.dT[i * RW + j] = v; });
     lds_barrier();
-    // G = T . Ng over the ahead bond: rows i = (e_, dk, dk1, l), columns f_
-    small_gemm_f64(L, Bs / (g * L), g, g,
-                   [&](int l, int i, int kk) { return k.dT[(i * g + kk) * L + l]; },
-                   [&](int l, int kk, int j) { return k.dNg[kk * g + j]; },
-                   [&](int l, int i, int j, double v) { k.dG[(i * g + j) * L + l] = v; });
+    // G = T . Ng over the ahead bond: rows i = (e_, dk, dk1), columns f_, the label is the batch
+    mm_lds(L, Bs / (g * L), g, g, k.dT, 1, g * L, L, k.dNg, 0, g, 1,
+           [&](int l, int i, int j, double v) { k.dG[(i * g + j) * L + l] = v; });
     lds_barrier();
   }
   TNML_STAMP(2);

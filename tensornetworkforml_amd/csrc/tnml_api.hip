@@ -893,7 +893,8 @@ static void fill_prev_operands(tnml_ctx *c, WideParams &w, int left_dir, int p_p
 static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float weight_dec, int l2_flag, int act_fn, int loss_fn,
                          float T, int trunc_policy) {
   const int N = c->N, D = c->D, L = c->L;
-  if (!c->persist_enabled || !c->pipe_enabled || c->comm || c->debug || c->stamps || c->profile || c->check_launches) return 0;
+  // (cycle stamps alone -- tnml_debug_enable(ctx, 2) -- are allowed: they are taken at the middle step of the sweep)
+  if (!c->persist_enabled || !c->pipe_enabled || c->comm || c->debug || c->profile || c->check_launches) return 0;
   if (trunc_policy == TNML_TRUNC_ADAPTIVE || n_steps != N - 1 || c->force_big) return 0;
   if (!c->f_current || c->Bnew_valid) return 0;
   // state the planning loop advances; restored if some step does not fit
@@ -971,6 +972,7 @@ static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float
     n.metrics = c->metrics + 2 * (size_t)k;
     n.svd_stop2 = c->svd_stop2; n.chol_thr = c->chol_thr;
     n.status = c->status; n.counters = c->counters;
+    n.stamps = (c->stamps && k == n_steps / 2) ? c->dbg + 4 * c->bmax + kDbgSigma + 5 : nullptr;
     n.pipe = 1; n.persist = 1; n.z_first = (k == 0);
     ps.w = WidePipeParams{};
     fill_wide_pipe(c, ps.w, left_dir, k, act_fn, loss_fn, T);
@@ -1011,12 +1013,29 @@ static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float
     c->prev_h = h; c->prev_g = g; c->prev_p = p;
     bytes += 4.0 * c->b * (2.0 * h + g + 3.0 * D + 2.0 * L + 1.0);
     flops += 4.0 * c->b * D * D * h * g * L + 2.0 * c->b * D * h * h;
-    c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
+    if (!c->stamps || k <= n_steps / 2) { c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir; }
   }
-  const size_t lds = std::max(std::max(lds_narrow + pbytes, lds_wide), lds_help);
+  size_t lds = std::max(std::max(lds_narrow + pbytes, lds_wide), lds_help);
   if (lds > 160 * 1024) return give_up();
+  // raw-gradient area of the staged front end: between the largest carve and the persistent region, if the launch has the room
+  size_t raw_bytes = 0;
+  for (int k = 0; k < n_steps; ++k) raw_bytes = std::max(raw_bytes, (size_t)st[k].n.bsize * sizeof(float) + 16);
+  const bool have_raw = lds_narrow + raw_bytes + pbytes <= 160 * 1024;
+  if (have_raw) lds = std::max(lds, lds_narrow + raw_bytes + pbytes);
   const int persist_off = (int)((lds - pbytes) & ~(size_t)15);
-  for (int k = 0; k < n_steps; ++k) st[k].n.persist_off = persist_off;
+  const int raw_off = (int)((persist_off - raw_bytes) & ~(size_t)15);
+  for (int k = 0; k < n_steps; ++k) {
+    NarrowParams &n = st[k].n;
+    n.persist_off = persist_off;
+    // staging rooms (kernels_narrow.hip: narrow_carve): Z_k [zr][RW] floats from fBp up to the integer tables, T_k [zr][RW] doubles in the
+    // Jacobi / update region
+    const int r = D * n.h, cc = D * n.g * L, nn = std::min(r, cc), ne = nn + (nn & 1);
+    const size_t RW = (size_t)D * D * n.g * L, Bs = (size_t)n.bsize;
+    const size_t zreg = std::max(2 * Bs, (size_t)4 * ne * ne);
+    const size_t room = Bs + nn + 4 + (size_t)n.h * D * n.s * L + (size_t)n.s * D * n.g + (size_t)r * n.m + (size_t)n.m * cc;
+    n.stage_lds = have_raw && (size_t)n.zr * RW <= zreg && (size_t)n.zr * RW <= room && ((n.zr * RW) & 3) == 0;
+    n.raw_off = raw_off;
+  }
   // ---- enqueue: records, zeroed flags and counters, one launch
   HIP_TRY(hipMemcpyAsync(c->pst_dev, st, (size_t)n_steps * sizeof(PersistStep), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->pro_dev, &pro, sizeof(WidePipeParams), hipMemcpyHostToDevice, c->stream));

@@ -123,6 +123,8 @@ struct NarrowParams {
   int zr;                  // rows of Z_k and T_k: D * (behind bond of step k-1), 1 at k == 0
   int write_ahead;         // the new label core is wanted (last step of the launch); otherwise its product is skipped
   int persist_off;         // byte offset of the persistent LDS region (PersistLds), Mcap its capacity per bond
+  int stage_lds;           // Z_k and T_k fit the LDS regions that are dead at the start of the step: staged there (else: operands from memory)
+  int raw_off;             // byte offset of the raw-gradient area [h][RW] floats (stage_lds)
   int Mcap;
   const double *Tsrc;      // T_k[zr][D][D][g][L] (float64: exact sums of float32 products), written by the helper workgroup of this launch
   const unsigned *zready;  // >= zwant: Z_k (zred) is complete;  tready >= twant: T_k is complete

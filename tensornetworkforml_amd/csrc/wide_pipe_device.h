@@ -98,6 +98,17 @@ __device__ inline int spin_wait_ge(const unsigned *flag, unsigned want, const un
   return 1;
 }
 
+// the same for two flags at once (both polls in flight together)
+__device__ inline int spin_wait_ge2(const unsigned *f1, unsigned w1, const unsigned *f2, unsigned w2, const unsigned *abort_flag) {
+  for (int spins = 0; spins < (1 << 22); ++spins) {
+    const unsigned a = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a >= w1 && b >= w2) return 0;
+    if ((spins & 63) == 63 && abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 2;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return 1;
+}
+
 struct WidePipeDims { int nI, IP, JP, RS, KA, HS, I3, J3, EH; };
 template <class WP>
 __host__ __device__ inline WidePipeDims wide_pipe_dims(const WP &p) {
