@@ -207,110 +207,33 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
   // a loop of dependent load -> LDS-store iterations costs one round trip per iteration (7 for the reduced pre-gradient).
   const bool fast0 = p.pipe && !p.persist && (size_t)p.z_rows * RWz + (size_t)p.z_rows * h <= (size_t)((float *)k.sOrd - k.fBp) &&
                      Bs <= 8 * NT && p.z_rows * RWz <= 16 * NT && p.z_rows * h <= 4 * NT && h * h <= 2 * NT && g * g <= 2 * NT;
-  // ---- persistent sweep: merged tensor and raw gradient of this step as projections with the previous step's behind core ----
-  //   B_k      = diag(1 / sigma) A'^T . T_k,   T_k[i, d, d', g, l] = sum_s B_new(k-1)[i, d, s, l] pl_{k+1}[s, d', g]   (helper workgroup)
-  //   dB_raw_k =                 A'^T . Z_k                                                                       (batch-side workgroups)
-  // A' = U sqrt(S) [D h_{k-1}][h] and 1 / sigma stay in LDS from the end of step k-1 (identity at k == 0, where T_0 = A_0 . A_1 and
-  // Z_0 is the gradient itself).  The right-hand operands go from memory straight into the MFMA operand registers (agent-scope
-  // loads, every k-step of a column tile in flight at once): no staging, one barrier.
+  // ---- persistent sweep: merged tensor, L2 term and raw gradient of this step are projections with the previous step's behind core,
+  //   B_k = diag(1 / sigma) A'^T . T_k,   (Ln.B.Rn)_k = Nh^T . diag(1 / sigma) A'^T . (T_k . Ng),   dB_raw_k = A'^T . Z_k,
+  // formed by the helper workgroups of the launch (persist_helper_block), each for a slice of the columns, from operands they
+  // prepared beside the previous SVD; this workgroup waits for their arrival counter and loads the three results.
   const PersistLds PL = persist_lds(smem_raw + p.persist_off, p.Mcap);
   float *sRaw = k.fBp;                          // raw gradient [h][RW] (float): dead before phase 5 rewrites fBp
   if (p.persist) {
     if (tid == 0) {
-      int bad = spin_wait_ge2(p.zready, p.zwant, p.tready, p.twant, p.abort_flag);
+      const int bad = spin_wait_ge(p.pready, p.pwant, p.abort_flag);
       if (bad == 1) { atomicOr(p.status, 4); __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       k.sFlag[3] = bad;
     }
     lds_barrier();
     if (k.sFlag[3]) return true;
-    if (p.stamps && tid == 0) p.stamps[20] = (double)(__builtin_amdgcn_s_memtime() - t_c0);      // flags seen
+    if (p.stamps && tid == 0) { p.stamps[20] = (double)(__builtin_amdgcn_s_memtime() - t_c0); p.stamps[28] = (double)(t_r0 & ((1ull << 40) - 1)); p.stamps[29] = (double)(__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1)); }
     if (tid < kMetricSlots) k.sTail[tid] = ld_sc1(p.zred + p.zsize + tid);
     for (int e = tid; e < h * h; e += NT) k.dNh[e] = p.Nh ? PL.Nh[e] : 1.0;
-    for (int e = tid; e < g * g; e += NT) k.dNg[e] = p.Ng ? p.Ng[e] : 1.0;
-    const int zr = p.zr, RW = RWz;
-    if (p.stage_lds) {
-      // Both operands through LDS (the launcher checked the room: Z_k over the region of the padded matrix copy and the two
-      // cores, T_k over the Jacobi buffers, all dead here; the raw gradient goes to its own area): ONE round trip of 16-byte
-      // agent-scope loads, then the two products on LDS operands, tiles dealt over all waves.
-      sRaw = reinterpret_cast<float *>(smem_raw + p.raw_off);
-      float *sZs = k.fBp;
-      double *sTs = k.Z;
-      const int nz4 = (zr * RW) >> 2, nt2 = (zr * RW) >> 1;
-      const __amdgpu_buffer_rsrc_t rZ = sc1_rsrc(p.zred), rT = sc1_rsrc(p.Tsrc);
-      tn_uvec4 qz[2], qt[4];
+    const __amdgpu_buffer_rsrc_t rR = sc1_rsrc(p.prepRaw), rB = sc1_rsrc(p.prepB), rG = sc1_rsrc(p.prepG);
+    tn_uvec4 qr[2], qb[2], qg[4];                // Bs <= 8192 (launcher), a multiple of 4
 #pragma unroll
-      for (int u = 0; u < 2; ++u) { const int e = tid + u * NT; if (e < nz4) qz[u] = ld_sc1_b128(rZ, (unsigned)e * 16u); }
+    for (int u = 0; u < 2; ++u) { const int e = 4 * (tid + u * NT); if (e < Bs) { qr[u] = ld_sc1_b128(rR, (unsigned)e * 4u); qb[u] = ld_sc1_b128(rB, (unsigned)e * 4u); } }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int e = tid + u * NT; if (e < nt2) qt[u] = ld_sc1_b128(rT, (unsigned)e * 16u); }
+    for (int u = 0; u < 4; ++u) { const int e = 2 * (tid + u * NT); if (p.l2_flag && e < Bs) qg[u] = ld_sc1_b128(rG, (unsigned)e * 8u); }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) { const int e = tid + u * NT; if (e < nz4) *reinterpret_cast<tn_uvec4 *>(sZs + 4 * e) = qz[u]; }
+    for (int u = 0; u < 2; ++u) { const int e = 4 * (tid + u * NT); if (e < Bs) { *reinterpret_cast<tn_uvec4 *>(sRaw + e) = qr[u]; *reinterpret_cast<tn_uvec4 *>(k.fB + e) = qb[u]; } }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int e = tid + u * NT; if (e < nt2) *reinterpret_cast<tn_uvec4 *>(sTs + 2 * e) = qt[u]; }
-      for (int e = tid + 2 * NT; e < nz4; e += NT) *reinterpret_cast<tn_uvec4 *>(sZs + 4 * e) = ld_sc1_b128(rZ, (unsigned)e * 16u);
-      for (int e = tid + 4 * NT; e < nt2; e += NT) *reinterpret_cast<tn_uvec4 *>(sTs + 2 * e) = ld_sc1_b128(rT, (unsigned)e * 16u);
-      lds_barrier();
-      if (p.stamps && tid == 0) p.stamps[21] = (double)(__builtin_amdgcn_s_memtime() - t_c0);    // operands in LDS
-      mm_lds_f32(h, RW, zr, PL.A, 1, h, sZs, RW, 1, [&](int i, int j, float v) { sRaw[i * RW + j] = v; });
-      const int tiles32 = ((h + 15) >> 4) * ((RW + 15) >> 4);
-      mm_lds(1, h, RW, zr, PL.Ad, 0, 1, h, sTs, 0, RW, 1,
-             [&](int, int i, int j, double v) { k.fB[i * RW + j] = (float)(v * PL.invs[i]); }, false, tiles32 & ((NT >> 6) - 1));
-    } else {
-    const int lane = tid & 63, rr = lane & 15, qq = lane >> 4;
-    const int ncol = (RW + 15) >> 4, nk = (zr + 3) >> 2, tmh = (h + 15) >> 4;
-    constexpr int kMaxK = 16;                    // zr <= 64 (launcher)
-    for (int item = wave_u; item < 2 * ncol; item += NT >> 6) {
-      const bool isT = item >= ncol;
-      const int ct = isT ? item - ncol : item;
-      const int col = min(ct * 16 + rr, RW - 1), j = ct * 16 + rr;
-      if (!isT) {                                 // raw gradient: float32 operands, float32 matrix pipe (as the per-step path)
-        float bv[kMaxK];
-#pragma unroll
-        for (int ks = 0; ks < kMaxK; ++ks) {
-          const int row = 4 * ks + qq;
-          bv[ks] = (ks < nk && row < zr) ? ld_sc1(p.zred + (size_t)row * RW + col) : 0.f;
-        }
-        for (int ti = 0; ti < tmh; ++ti) {
-          const int hh = min(ti * 16 + rr, h - 1);
-          fvec4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < kMaxK; ++ks) {
-            if (ks >= nk) break;
-            const int row = 4 * ks + qq;
-            const float a = row < zr ? PL.A[row * h + hh] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[ks], acc, 0, 0, 0);
-          }
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int i = ti * 16 + 4 * qq + reg;
-            if (i < h && j < RW) sRaw[i * RW + j] = acc[reg];
-          }
-        }
-      } else {                                    // merged tensor: float64 throughout (see PersistLds::Ad)
-        double bv[kMaxK];
-#pragma unroll
-        for (int ks = 0; ks < kMaxK; ++ks) {
-          const int row = 4 * ks + qq;
-          bv[ks] = (ks < nk && row < zr) ? __hip_atomic_load(p.Tsrc + (size_t)row * RW + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        }
-        for (int ti = 0; ti < tmh; ++ti) {
-          const int hh = min(ti * 16 + rr, h - 1);
-          dvec4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int ks = 0; ks < kMaxK; ++ks) {
-            if (ks >= nk) break;
-            const int row = 4 * ks + qq;
-            const double a = row < zr ? PL.Ad[row * h + hh] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[ks], acc, 0, 0, 0);
-          }
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int i = ti * 16 + qq + 4 * reg;
-            if (i < h && j < RW) k.fB[i * RW + j] = (float)(acc[reg] * PL.invs[i]);
-          }
-        }
-      }
-    }
-    }
+    for (int u = 0; u < 4; ++u) { const int e = 2 * (tid + u * NT); if (p.l2_flag && e < Bs) *reinterpret_cast<tn_uvec4 *>(k.dG + e) = qg[u]; }
   }
   float *sZ = k.fBp, *sZc = sZ + (size_t)p.z_rows * RWz;
   if (fast0) {
@@ -469,7 +392,7 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
 
   TNML_STAMP(1);
   // ---- phases 2-3: weight decay term ------------------------------------------------------------
-  if (p.l2_flag && !p.fused && !p.prep_ready) {
+  if (p.l2_flag && !p.fused && !p.prep_ready && !p.persist) {
     // T = Nh^T . B over the behind bond:  T[e_, rest] = sum_a Nh[a, e_] B[a, rest]
     mm_lds(1, h, RW, h, k.dNh, 0, 1, h, k.fB, 0, RW, 1, [&](int, int i, int j, double v) { k.dT[i * RW + j] = v; });
     lds_barrier();
@@ -1158,11 +1081,19 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
     if (ldtail(2) != 0.f) atomicOr(p.status, 1);
   }
   if (p.persist) {
-    // what the next step of the sweep needs from this one stays in LDS: the behind core, 1 / sigma, (the norm environment went there
-    // from its product); the behind core in memory is complete once every storing wave has drained -> flag for the batch side
-    lds_barrier();                                           // sCb complete (long-side product of the !short_rows case)
-    for (int e = tid; e < r * mk; e += NT) PL.A[e] = k.sCb[e];
-    for (int sp = tid; sp < mk; sp += NT) { const double iq = k.dSq[ne + sp]; PL.invs[sp] = iq * iq; }
+    // The next step's projections are formed by the helper workgroups: they get the behind core before its rounding to float32
+    // (the projection divides by sigma: rounding errors of A' would come back multiplied by sigma_max / sigma_j), 1 / sigma and
+    // the behind norm environment of the next step; the batch-side workgroups extend their environments with the float32 core in
+    // its slot.  Everything leaves with agent-scope stores; every wave drains, the workgroup meets, one lane raises the flag.
+    lds_barrier();                                           // PL.Ad, PL.Nh complete
+    double *pub = p.Apub;                                    // [r * mk] A', [mk] 1 / sigma, [mk * mk] Nh
+    for (int e = tid; e < r * mk; e += NT) __hip_atomic_store(pub + e, PL.Ad[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int sp = tid; sp < mk; sp += NT) {
+      const double iq = k.dSq[ne + sp];
+      __hip_atomic_store(pub + r * mk + sp, iq * iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (p.Nh_new)
+      for (int e = tid; e < mk * mk; e += NT) __hip_atomic_store(pub + r * mk + mk + e, PL.Nh[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     if (tid == 0) __hip_atomic_store(p.coreflag, p.coretoken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1211,89 +1142,166 @@ void launch_step_pipe(const NarrowParams &p, const WidePipeParams &w, size_t lds
 // flag; relaxed poll, barrier, agent-scope loads) on flags that only grow; every wait is bounded and gives up for the whole
 // launch through one abort word, so the grid always drains.
 // ------------------------------------------------------------------------------------------------------------------
+// One helper workgroup of a persistent sweep, one call per step k.  Two parts:
+//   (1) [beside the SVD of step k-1, once B_new(k-1) is stored]  its ROW slice of
+//         T_k[i, d, (d', g), l]  = sum_s W[i, d, s, l] A_{k+1}(s, (d', g))       W = B_new(k-1) as [(h, d_{k-1}), d_k, s, l]; the label core at k == 0
+//         TN_k[i, d, d', g', l]  = sum_g T_k[i, d, d', g, l] Ng[g, g']
+//       in float64 (exact sums of float32 products), written to memory for everybody;
+//   (2) [once the update workgroup has published A' = U sqrt(S), 1 / sigma and Nh of step k-1, every helper has finished (1) and the
+//       pre-gradient Z_k is reduced]  its COLUMN slice of
+//         dB_raw = A'^T Z_k,   B_k = diag(1 / sigma) A'^T T_k,   (Ln.B.Rn)_k = Nh^T diag(1 / sigma) A'^T TN_k
+//       -> prepRaw / prepB / prepG, then its arrival.
+// (2) of step k is the only part on the critical path of the sweep: three 2 x 2-tile products and one more, on LDS operands.
 template <class HP>
-__device__ inline bool persist_helper_block(const HP &t, unsigned char *smem_raw) {
+__device__ __forceinline__ bool persist_helper_block(const HP &t, int hid, int nH, unsigned char *smem_raw, bool do_part2) {
   const int tid = threadIdx.x, NT = kNarrowThreads;
-  const int D = kD, zr = t.zr, s = t.s, g = t.g, L = t.L;
-  float *sW = (float *)smem_raw;                           // [zr D][s][L]   rows (i, d) of W_{k-1}
-  const int nW = zr * D * s * L, nP = s * D * g, nT = zr * D * D * g * L;
-  float *sP = sW + ((nW + 3) & ~3);                        // [s][D g]       A_{k+1}(s, (d', g))
-  double *oT = (double *)(sP + ((nP + 3) & ~3));           // [zr D][D g][L] the result (float64), staged for 16-byte stores
+  const int D = kD, zr = t.zr, s = t.s, g = t.g, L = t.L, h = t.h;
+  const int DG = D * g, RW = D * DG * L;
   __shared__ int sBad;
-  if (tid == 0) {
-    const int bad = t.want ? spin_wait_ge(t.flag, t.want, t.abort_flag) : 0;
+  auto give_up = [&](int bad) {            // called by thread 0
     if (bad == 1) { atomicOr(t.status, 4); __hip_atomic_store(t.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     sBad = bad;
+  };
+  if (!do_part2) {
+    // ---------------- part 1: rows [r0, r1) of the zr * D rows (i, d) ----------------
+    const int R1 = zr * D, per = (R1 + nH - 1) / nH, r0 = min(R1, hid * per), nr = min(R1, r0 + per) - r0;
+    float *sW = (float *)smem_raw;                           // [nr][s][L]
+    float *sP = sW + (((size_t)per * s * L + 3) & ~(size_t)3);   // [s][D g]
+    double *sNg = (double *)(sP + (((size_t)s * DG + 3) & ~(size_t)3));   // [g][g]
+    double *oT = sNg + (((size_t)g * g + 1) & ~(size_t)1);   // [nr][D g][L]
+    double *oN = oT + (size_t)per * DG * L;                  // [nr][D][g][L]
+    if (tid == 0) give_up(t.want ? spin_wait_ge(t.flag, t.want, t.abort_flag) : 0);
+    lds_barrier();
+    if (sBad) return true;
+    if (nr > 0) {
+      const int nW = nr * s * L;
+      if (t.W) {
+        const float *Wsrc = t.W + (size_t)r0 * s * L;
+        for (int e = tid; e < nW; e += NT) sW[e] = ld_sc1(Wsrc + e);
+      } else {                                               // k == 0: the label core, rows d (zr == 1)
+        for (int e = tid; e < nW; e += NT) {
+          const int l = e % L, q = e / L, s_ = q % s, d = r0 + q / s;
+          sW[e] = t.lab.base[d * t.lab.s_d + s_ * t.lab.s_out + l];
+        }
+      }
+      for (int e = tid; e < s * DG; e += NT) {
+        const int g_ = e % g, q = e / g, d = q % D, s_ = q / D;
+        sP[e] = t.pl.base[s_ * t.pl.s_in + d * t.pl.s_d + g_ * t.pl.s_out];
+      }
+      if (t.l2_flag) for (int e = tid; e < g * g; e += NT) sNg[e] = t.Ng ? t.Ng[e] : 1.0;
+      lds_barrier();
+      mm_lds(L, nr, DG, s, sW, 1, s * L, L, sP, 0, DG, 1, [&](int l, int row, int col, double v) { oT[(row * DG + col) * L + l] = v; });
+      lds_barrier();
+      if (t.l2_flag)      // rows (row, d'), inner index g, columns g'
+        mm_lds(L, nr * D, g, g, oT, 1, g * L, L, sNg, 0, g, 1, [&](int l, int i, int j, double v) { oN[(i * g + j) * L + l] = v; });
+      // the row slice is one contiguous block of T_k (and of TN_k)
+      const int nT = nr * DG * L;
+      double *Tdst = t.T + (size_t)r0 * DG * L, *Ndst = t.TN + (size_t)r0 * DG * L;
+      for (int e = tid; e < nT; e += NT) __hip_atomic_store(Tdst + e, oT[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t.l2_flag) {
+        lds_barrier();
+        for (int e = tid; e < nT; e += NT) __hip_atomic_store(Ndst + e, oN[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (tid == 0) __hip_atomic_fetch_add(t.tcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+  }
+  // ---------------- part 2: columns [c0, c0 + nc) of the RW columns ----------------
+  const int cw = (RW + nH - 1) / nH, c0 = min(RW, hid * cw), nc = min(RW, c0 + cw) - c0;
+  double *sA = (double *)smem_raw;                           // [zr][h]  A' (float64)
+  double *sAf = sA + (size_t)zr * h;                         // [zr][h]  A' as stored (float32 values)
+  double *sIv = sAf + (size_t)zr * h;                        // [h]      1 / sigma
+  double *sNh = sIv + ((h + 1) & ~1);                        // [h][h]
+  double *sT = sNh + (((size_t)h * h + 1) & ~(size_t)1);     // [zr][cw]
+  double *sN = sT + (size_t)zr * cw;                         // [zr][cw]
+  double *sP2 = sN + (size_t)zr * cw;                        // [h][cw]  diag(1 / sigma) A'^T TN
+  float *sZc = (float *)(sP2 + (size_t)h * cw);              // [zr][cw]
+  double *hst = (t.stamps && hid == 0 && tid == 0) ? t.stamps : nullptr;
+  auto rt = []() { return (double)(__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1)); };
+  if (tid == 0) {
+    if (hst) hst[22] = rt();
+    int bad = t.awant ? spin_wait_ge(t.aflag, t.awant, t.abort_flag) : 0;
+    if (hst) hst[23] = rt();
+    if (!bad) bad = spin_wait_ge(t.tcnt, (unsigned)nH, t.abort_flag);
+    if (hst) hst[30] = rt();
+    if (!bad) bad = spin_wait_ge(t.zready, t.zwant, t.abort_flag);
+    if (hst) hst[24] = rt();
+    give_up(bad);
   }
   lds_barrier();
   if (sBad) return true;
-  if (t.W) {                                               // B_new(k-1), stored by the update workgroup of this launch
-    if ((nW & 3) == 0) {
-      const __amdgpu_buffer_rsrc_t rW = sc1_rsrc(t.W);
-      for (int e = 4 * tid; e < nW; e += 4 * NT) *reinterpret_cast<tn_uvec4 *>(sW + e) = ld_sc1_b128(rW, (unsigned)e * 4u);
-    } else {
-      for (int e = tid; e < nW; e += NT) sW[e] = ld_sc1(t.W + e);
+  if (nc > 0) {
+    if (t.awant) {
+      const double *pub = t.Apub;
+      for (int e = tid; e < zr * h; e += NT) {
+        const double a = __hip_atomic_load(pub + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sA[e] = a; sAf[e] = (double)(float)a;
+      }
+      for (int e = tid; e < h; e += NT) sIv[e] = __hip_atomic_load(pub + zr * h + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t.l2_flag) for (int e = tid; e < h * h; e += NT) sNh[e] = __hip_atomic_load(pub + zr * h + h + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tid == 0) {                                   // k == 0: zr == h == 1, the identity
+      sA[0] = 1.0; sAf[0] = 1.0; sIv[0] = 1.0; sNh[0] = 1.0;
     }
-  } else {                                                 // k == 0: the label core itself, (d, s, l)
-    for (int e = tid; e < nW; e += NT) {
-      const int l = e % L, q = e / L, s_ = q % s, d = q / s;
-      sW[e] = t.lab.base[d * t.lab.s_d + s_ * t.lab.s_out + l];
+    for (int e = tid; e < zr * nc; e += NT) {
+      const int i = e / nc, cc = e - i * nc;
+      const size_t src = (size_t)i * RW + c0 + cc;
+      sT[i * cw + cc] = __hip_atomic_load(t.T + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t.l2_flag) sN[i * cw + cc] = __hip_atomic_load(t.TN + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sZc[i * cw + cc] = ld_sc1(t.Z + src);
+    }
+    lds_barrier();
+    if (hst) hst[25] = rt();
+    // three independent products [h][nc] = A'^T [zr][nc], tiles dealt as one list
+    int slot = mm_lds(1, h, nc, zr, sAf, 0, 1, h, sZc, 0, cw, 1,
+                      [&](int, int i, int j, double v) { st_sc1(t.prepRaw + (size_t)i * RW + c0 + j, (float)v); });
+    slot = mm_lds(1, h, nc, zr, sA, 0, 1, h, sT, 0, cw, 1,
+                  [&](int, int i, int j, double v) { st_sc1(t.prepB + (size_t)i * RW + c0 + j, (float)(v * sIv[i])); }, false, slot);
+    if (t.l2_flag) {
+      mm_lds(1, h, nc, zr, sA, 0, 1, h, sN, 0, cw, 1, [&](int, int i, int j, double v) { sP2[i * cw + j] = v * sIv[i]; }, false, slot);
+      lds_barrier();
+      // (Ln.B.Rn)[e_, c] = sum_a Nh[a, e_] P2[a, c]
+      mm_lds(1, h, nc, h, sNh, 0, 1, h, sP2, 0, cw, 1,
+             [&](int, int i, int j, double v) { __hip_atomic_store(t.prepG + (size_t)i * RW + c0 + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
     }
   }
-  for (int e = tid; e < nP; e += NT) {
-    const int g_ = e % g, q = e / g, d = q % D, s_ = q / D;
-    sP[e] = t.pl.base[s_ * t.pl.s_in + d * t.pl.s_d + g_ * t.pl.s_out];
-  }
-  lds_barrier();
-  const int DG = D * g;
-  mm_lds(L, zr * D, DG, s, sW, 1, s * L, L, sP, 0, DG, 1,
-         [&](int l, int row, int col, double v) { oT[(row * DG + col) * L + l] = v; });
-  lds_barrier();
-  if ((nT & 1) == 0) {
-    const __amdgpu_buffer_rsrc_t rT = sc1_rsrc(t.T);
-    for (int e = 2 * tid; e < nT; e += 2 * NT) st_sc1_b128(rT, (unsigned)e * 8u, *reinterpret_cast<const tn_uvec4 *>(oT + e));
-  } else {
-    for (int e = tid; e < nT; e += NT) __hip_atomic_store(t.T + e, oT[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (hst) hst[26] = rt();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
-  if (tid == 0) __hip_atomic_store(t.tready, t.publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_fetch_add(t.pcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (hst) hst[27] = rt();
   return false;
 }
 
 typedef const __attribute__((address_space(4))) PersistStep ConstPersistStep;
-typedef const __attribute__((address_space(4))) WidePipeParams ConstWidePipeParams;
-__global__ __launch_bounds__(kNarrowThreads) void sweep_persist_kernel(const PersistStep *__restrict__ steps_g,
-                                                                       const WidePipeParams *__restrict__ pro_g, int n_steps) {
+__global__ __launch_bounds__(kNarrowThreads) void sweep_persist_kernel(const PersistStep *__restrict__ steps_g, int n_steps, int nH) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // the host wrote the records before the launch and nothing in the kernel writes them: constant address space -> scalar loads
-  ConstPersistStep *steps = (ConstPersistStep *)steps_g;
-  ConstWidePipeParams *pro = (ConstWidePipeParams *)pro_g;
+  ConstPersistStep *steps = (ConstPersistStep *)steps_g;         // [n_steps + 1]: the last record carries the prologue of the batch side
   const int blk = blockIdx.x;
   if (blk == 0) {
-    const PersistLds PL = persist_lds(smem_raw + steps[0].n.persist_off, steps[0].n.Mcap);
-    if (threadIdx.x == 0) { PL.A[0] = 1.f; PL.Ad[0] = 1.0; PL.invs[0] = 1.0; PL.Nh[0] = 1.0; }     // step 0 projects with the identity
-    lds_barrier();
-#pragma nounroll
     for (int k = 0; k < n_steps; ++k)
       if (narrow_body(steps[k].n, smem_raw)) break;
-  } else if (blk == 1) {
+  } else if (blk <= nH) {
+    // T_0; then per step: the projections of step k, and T_{k+1} once B_new(k) is there -- one call site (the body is inlined once)
 #pragma nounroll
-    for (int k = 0; k < n_steps; ++k)
-      if (persist_helper_block(steps[k].t, smem_raw)) break;
+    for (int ph = 0; ph < 2 * n_steps; ++ph) {
+      lds_barrier();
+      if (persist_helper_block(steps[ph >> 1].t, blk - 1, nH, smem_raw, (ph & 1) != 0)) break;
+    }
   } else {
-    if (wide_pipe_block(*pro, (float *)smem_raw)) return;
+    // Z_0 from forward's f (record n_steps), then one iteration per step -- one call site
 #pragma nounroll
-    for (int k = 0; k < n_steps; ++k) {
-      lds_barrier();                                       // the previous step's LDS arrays are dead
-      if (wide_pipe_block(steps[k].w, (float *)smem_raw)) break;
+    for (int it = 0; it <= n_steps; ++it) {
+      lds_barrier();                                       // the previous iteration's LDS arrays are dead
+      if (wide_pipe_block(steps[it == 0 ? n_steps : it - 1].w, (float *)smem_raw)) break;
     }
   }
 }
 
-void launch_sweep_persist(const PersistStep *steps_dev, const WidePipeParams *pro_dev, int n_steps, int grid, size_t lds_bytes,
-                          hipStream_t st) {
-  hipLaunchKernelGGL(sweep_persist_kernel, dim3(grid), dim3(kNarrowThreads), lds_bytes, st, steps_dev, pro_dev, n_steps);
+void launch_sweep_persist(const PersistStep *steps_dev, int n_steps, int n_helpers, int grid, size_t lds_bytes, hipStream_t st) {
+  hipLaunchKernelGGL(sweep_persist_kernel, dim3(grid), dim3(kNarrowThreads), lds_bytes, st, steps_dev, n_steps, n_helpers);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -116,11 +116,10 @@ struct tnml_ctx {
   // reduced pre-gradient, T_k buffers, per-step arrival counters, the flag words of the launch
   bool persist_enabled = true;               // tnml_set_persistent
   PersistStep *pst_dev = nullptr, *pst_host[2] = {nullptr, nullptr};
-  WidePipeParams *pro_dev = nullptr, *pro_host[2] = {nullptr, nullptr};
   hipEvent_t pst_ev[2] = {nullptr, nullptr};
   int pst_cur = 0;
-  float *zred2 = nullptr;
-  double *Tbuf[2] = {nullptr, nullptr};
+  float *zred2 = nullptr, *prepRaw = nullptr;
+  double *Tbuf[2] = {nullptr, nullptr}, *TNbuf[2] = {nullptr, nullptr}, *Apub = nullptr;
   unsigned *pst_cnt = nullptr, *pst_flags = nullptr;
   long long persist_sweeps = 0;
   int num_cus = 256;
@@ -244,11 +243,13 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipMalloc(&c->zred2, (size_t)c->zstride * sizeof(float)));
   HIP_TRY(hipMalloc(&c->Tbuf[0], (size_t)c->zstride * sizeof(double)));
   HIP_TRY(hipMalloc(&c->Tbuf[1], (size_t)c->zstride * sizeof(double)));
-  HIP_TRY(hipMalloc(&c->pst_dev, (size_t)N * sizeof(PersistStep)));
-  HIP_TRY(hipMalloc(&c->pro_dev, sizeof(WidePipeParams)));
+  HIP_TRY(hipMalloc(&c->TNbuf[0], (size_t)c->zstride * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->TNbuf[1], (size_t)c->zstride * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->prepRaw, c->bmax * sizeof(float)));
+  HIP_TRY(hipMalloc(&c->Apub, ((size_t)D * Mmax * Mmax + Mmax + (size_t)Mmax * Mmax + 8) * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->pst_dev, (size_t)(N + 1) * sizeof(PersistStep)));
   for (int i = 0; i < 2; ++i) {
-    HIP_TRY(hipHostMalloc(&c->pst_host[i], (size_t)N * sizeof(PersistStep)));
-    HIP_TRY(hipHostMalloc(&c->pro_host[i], sizeof(WidePipeParams)));
+    HIP_TRY(hipHostMalloc(&c->pst_host[i], (size_t)(N + 1) * sizeof(PersistStep)));
     HIP_TRY(hipEventCreateWithFlags(&c->pst_ev[i], hipEventDisableTiming));
   }
   HIP_TRY(hipMalloc(&c->pst_cnt, (size_t)(N + 1) * 32 * sizeof(unsigned)));
@@ -282,11 +283,10 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
                   c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2,
                   c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->zslabs, c->gslabs, c->zred, c->pipe_cnt, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
   for (void *p : ptrs) if (p) (void)hipFree(p);
-  void *pptrs[] = {c->zred2, c->Tbuf[0], c->Tbuf[1], c->pst_dev, c->pro_dev, c->pst_cnt, c->pst_flags};
+  void *pptrs[] = {c->zred2, c->Tbuf[0], c->Tbuf[1], c->TNbuf[0], c->TNbuf[1], c->prepRaw, c->Apub, c->pst_dev, c->pst_cnt, c->pst_flags};
   for (void *p : pptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 2; ++i) {
     if (c->pst_host[i]) (void)hipHostFree(c->pst_host[i]);
-    if (c->pro_host[i]) (void)hipHostFree(c->pro_host[i]);
     if (c->pst_ev[i]) (void)hipEventDestroy(c->pst_ev[i]);
   }
   for (int i = 0; i < tnml_ctx::kStageSlots; ++i) { if (c->stageX[i]) (void)hipFree(c->stageX[i]); if (c->stageY[i]) (void)hipFree(c->stageY[i]); }
@@ -904,22 +904,24 @@ static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float
   const int buf = c->pst_cur;
   HIP_TRY(hipEventSynchronize(c->pst_ev[buf]));              // the copy that last read this staging buffer is done
   PersistStep *st = c->pst_host[buf];
-  WidePipeParams &pro = *c->pro_host[buf];
+  st[n_steps] = PersistStep{};
+  WidePipeParams &pro = st[n_steps].w;                       // the batch side's prologue rides in the record after the last step
   double *nbeh = left_dir ? c->Rn : c->Ln, *nahe = left_dir ? c->Ln : c->Rn;
   const int ntiles = c->b_pad / kTS;
   const int tpw = ntiles >= 64 ? std::max(c->pipe_tpw, c->pipe_tiles) : c->pipe_tpw;
   const int nwide = (ntiles + tpw - 1) / tpw;
-  if (2 + nwide > c->num_cus) return 0;                      // every workgroup of the launch must be resident
+  const int nH = kPersistHelpers;
+  if (1 + nH + nwide > c->num_cus) return 0;                 // every workgroup of the launch must be resident
   const int Mcap = c->Mmax;
   const size_t pbytes = persist_lds_bytes(Mcap);
-  unsigned *fl = c->pst_flags;                               // [0] B_new token, [1] T ready, [2] Z ready, [3] behind core stored, [4] abort
+  unsigned *fl = c->pst_flags;                               // [0] B_new token, [2] Z ready, [3] behind core / Apub stored, [4] abort
   float *zr2[2] = {c->zred, c->zred2};
   size_t lds_narrow = 0, lds_wide = 0, lds_help = 0;
   // prologue: Z_0 from forward's f
   fill_wide_pipe(c, pro, left_dir, -1, act_fn, loss_fn, T);
   pro.do_ext = 0; pro.wait_flag = 0; pro.do_z = 1; pro.do_f = 0;
   pro.tiles_per_wg = tpw; pro.nwide = nwide; pro.ngroups = (nwide + kPipeGroupMax - 1) / kPipeGroupMax; pro.gsz = kPipeGroupMax;
-  pro.wg0 = 2; pro.persist = 1; pro.zred = zr2[0]; pro.zready = fl + 2; pro.zpublish = 1; pro.abort_flag = fl + 4;
+  pro.wg0 = 1 + nH; pro.persist = 1; pro.zred = zr2[0]; pro.zready = fl + 2; pro.zpublish = 1; pro.abort_flag = fl + 4;
   pro.gcnt = c->pst_cnt + (size_t)n_steps * 32; pro.tcnt = pro.gcnt + 16;
   if (!wide_pipe_fits(c, pro)) return give_up();
   if (pro.nwide <= 256 && (size_t)16 * (pro.zsize + kMetricSlots) * sizeof(float) <= wide_pipe_lds_bytes(pro) - 16) { pro.gsz = pro.nwide; pro.ngroups = 1; pro.one_level = 1; }
@@ -977,12 +979,14 @@ static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float
     ps.w = WidePipeParams{};
     fill_wide_pipe(c, ps.w, left_dir, k, act_fn, loss_fn, T);
     WidePipeParams &wp = ps.w;
-    n.zr = k == 0 ? 1 : wp.hprev * D;
-    if (n.zr > 64) return give_up();
-    n.z_rows = n.zr; n.zsize = n.zr * D * D * g * L;
-    n.zred = zr2[k & 1]; n.red = n.zred; n.Tsrc = c->Tbuf[k & 1];
-    n.zready = fl + 2; n.zwant = (unsigned)k + 1; n.tready = fl + 1; n.twant = (unsigned)k + 1;
+    const int zr = k == 0 ? 1 : wp.hprev * D;
+    if (zr > 64) return give_up();
+    n.z_rows = zr; n.zsize = zr * D * D * g * L;
+    n.zred = zr2[k & 1]; n.red = n.zred;
+    n.prepB = c->prepB; n.prepG = c->prepG; n.prepRaw = c->prepRaw;
+    n.pready = c->pst_cnt + (size_t)k * 32 + 21; n.pwant = (unsigned)nH;
     n.flag = fl + 0; n.token = (unsigned)k + 1;
+    n.Apub = c->Apub;
     n.coreflag = fl + 3; n.coretoken = (unsigned)k + 1; n.abort_flag = fl + 4;
     n.Mcap = Mcap;
     lds_narrow = std::max(lds_narrow, nlds);
@@ -990,22 +994,26 @@ static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float
     wp.do_ext = k >= 1; wp.do_f = 1; wp.wait_flag = 1;
     wp.do_z = (k + 1 <= N - 2);
     wp.tiles_per_wg = tpw; wp.nwide = nwide; wp.ngroups = (nwide + kPipeGroupMax - 1) / kPipeGroupMax; wp.gsz = kPipeGroupMax;
-    wp.wg0 = 2; wp.persist = 1; wp.flag = fl + 0; wp.token = (unsigned)k + 1;
+    wp.wg0 = 1 + nH; wp.persist = 1; wp.flag = fl + 0; wp.token = (unsigned)k + 1;
     wp.coreflag = fl + 3; wp.corewant = (unsigned)k; wp.zready = fl + 2; wp.zpublish = (unsigned)k + 2; wp.abort_flag = fl + 4;
     wp.zred = zr2[(k + 1) & 1];
     wp.gcnt = c->pst_cnt + (size_t)k * 32; wp.tcnt = wp.gcnt + 16;
+    wp.stamps = n.stamps;
     if (!wide_pipe_fits(c, wp)) return give_up();
     if (wp.do_z && wp.nwide <= 256 && (size_t)16 * (wp.zsize + kMetricSlots) * sizeof(float) <= wide_pipe_lds_bytes(wp) - 16) { wp.gsz = wp.nwide; wp.ngroups = 1; wp.one_level = 1; }
     lds_wide = std::max(lds_wide, wide_pipe_lds_bytes(wp));
-    // ---- helper workgroup: T_k
+    // ---- helper workgroups: T_k, T_k . Ng beside the SVD of step k-1; the three projections once its behind core is published
     PersistHelperParams &t = ps.t;
-    t.zr = n.zr; t.s = s; t.g = g; t.L = L;
+    t.zr = zr; t.s = s; t.g = g; t.L = L; t.h = h; t.l2_flag = n.l2_flag;
     t.W = k == 0 ? nullptr : c->Bnew;
-    t.lab = n.lab; t.pl = n.pl;
-    t.T = c->Tbuf[k & 1];
-    t.flag = fl + 0; t.want = (unsigned)k; t.tready = fl + 1; t.publish = (unsigned)k + 1; t.abort_flag = fl + 4; t.status = c->status;
-    lds_help = std::max(lds_help, persist_helper_lds_bytes(t.zr, s, g, L));
-    if ((size_t)t.zr * D * D * g * L + kMetricSlots > (size_t)c->zstride) return give_up();
+    t.lab = n.lab; t.pl = n.pl; t.Ng = n.Ng;
+    t.T = c->Tbuf[k & 1]; t.TN = c->TNbuf[k & 1]; t.Z = zr2[k & 1];
+    t.prepRaw = c->prepRaw; t.prepB = c->prepB; t.prepG = c->prepG; t.Apub = c->Apub;
+    t.flag = fl + 0; t.want = (unsigned)k; t.aflag = fl + 3; t.awant = (unsigned)k; t.zready = fl + 2; t.zwant = (unsigned)k + 1;
+    t.tcnt = c->pst_cnt + (size_t)k * 32 + 20; t.pcnt = c->pst_cnt + (size_t)k * 32 + 21;
+    t.abort_flag = fl + 4; t.status = c->status; t.stamps = n.stamps;
+    lds_help = std::max(lds_help, persist_helper_lds_bytes(zr, s, g, L, h, nH));
+    if ((size_t)zr * D * D * g * L + kMetricSlots > (size_t)c->zstride) return give_up();
     // ---- the bookkeeping of the per-step path
     c->bond[p] = m;
     c->l_pos = sa;
@@ -1015,35 +1023,17 @@ static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float
     flops += 4.0 * c->b * D * D * h * g * L + 2.0 * c->b * D * h * h;
     if (!c->stamps || k <= n_steps / 2) { c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir; }
   }
-  size_t lds = std::max(std::max(lds_narrow + pbytes, lds_wide), lds_help);
+  const size_t lds = std::max(std::max(lds_narrow + pbytes, lds_wide), lds_help);
   if (lds > 160 * 1024) return give_up();
-  // raw-gradient area of the staged front end: between the largest carve and the persistent region, if the launch has the room
-  size_t raw_bytes = 0;
-  for (int k = 0; k < n_steps; ++k) raw_bytes = std::max(raw_bytes, (size_t)st[k].n.bsize * sizeof(float) + 16);
-  const bool have_raw = lds_narrow + raw_bytes + pbytes <= 160 * 1024;
-  if (have_raw) lds = std::max(lds, lds_narrow + raw_bytes + pbytes);
   const int persist_off = (int)((lds - pbytes) & ~(size_t)15);
-  const int raw_off = (int)((persist_off - raw_bytes) & ~(size_t)15);
-  for (int k = 0; k < n_steps; ++k) {
-    NarrowParams &n = st[k].n;
-    n.persist_off = persist_off;
-    // staging rooms (kernels_narrow.hip: narrow_carve): Z_k [zr][RW] floats from fBp up to the integer tables, T_k [zr][RW] doubles in the
-    // Jacobi / update region
-    const int r = D * n.h, cc = D * n.g * L, nn = std::min(r, cc), ne = nn + (nn & 1);
-    const size_t RW = (size_t)D * D * n.g * L, Bs = (size_t)n.bsize;
-    const size_t zreg = std::max(2 * Bs, (size_t)4 * ne * ne);
-    const size_t room = Bs + nn + 4 + (size_t)n.h * D * n.s * L + (size_t)n.s * D * n.g + (size_t)r * n.m + (size_t)n.m * cc;
-    n.stage_lds = have_raw && (size_t)n.zr * RW <= zreg && (size_t)n.zr * RW <= room && ((n.zr * RW) & 3) == 0;
-    n.raw_off = raw_off;
-  }
+  for (int k = 0; k < n_steps; ++k) st[k].n.persist_off = persist_off;
   // ---- enqueue: records, zeroed flags and counters, one launch
-  HIP_TRY(hipMemcpyAsync(c->pst_dev, st, (size_t)n_steps * sizeof(PersistStep), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->pro_dev, &pro, sizeof(WidePipeParams), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->pst_dev, st, (size_t)(n_steps + 1) * sizeof(PersistStep), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->pst_ev[buf], c->stream));
   c->pst_cur ^= 1;
   HIP_TRY(hipMemsetAsync(c->pst_flags, 0, 8 * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->pst_cnt, 0, (size_t)(n_steps + 1) * 32 * sizeof(unsigned), c->stream));
-  launch_sweep_persist(c->pst_dev, c->pro_dev, n_steps, 2 + nwide, lds, c->stream);
+  launch_sweep_persist(c->pst_dev, n_steps, nH, 1 + nH + nwide, lds, c->stream);
   HIP_TRY(hipGetLastError());
   c->prev_left_dir = left_dir;
   c->cnt_steps += n_steps; c->cnt_bytes += bytes; c->cnt_flops += flops;

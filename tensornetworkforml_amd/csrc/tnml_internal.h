@@ -116,39 +116,31 @@ struct NarrowParams {
   CoreView zcore;          // A_{k-1}(h_{k-1}, d, h_k)
   unsigned *flag;          // if set: B_new is stored with agent-scope stores and `token` is written here afterwards
   unsigned token;
-  // persistent sweep (sweep_persist_kernel, kernels_narrow.hip): the workgroup loops over the steps of a sweep; the merged tensor
-  // and the raw gradient of step k are projections of T_k (helper workgroup) and Z_k (batch-side workgroups) with the behind
-  // core of step k-1, which stays in LDS together with 1 / sigma and the behind norm environment
+  // persistent sweep (sweep_persist_kernel, kernels_narrow.hip): the workgroup loops over the steps of a sweep; merged tensor, L2 term
+  // and raw gradient of step k come from the helper workgroups of the launch (projections with the behind core of step k-1)
   int persist;             // 1: called from sweep_persist_kernel (pipe == 1 as well)
-  int zr;                  // rows of Z_k and T_k: D * (behind bond of step k-1), 1 at k == 0
   int write_ahead;         // the new label core is wanted (last step of the launch); otherwise its product is skipped
   int persist_off;         // byte offset of the persistent LDS region (PersistLds), Mcap its capacity per bond
-  int stage_lds;           // Z_k and T_k fit the LDS regions that are dead at the start of the step: staged there (else: operands from memory)
-  int raw_off;             // byte offset of the raw-gradient area [h][RW] floats (stage_lds)
   int Mcap;
-  const double *Tsrc;      // T_k[zr][D][D][g][L] (float64: exact sums of float32 products), written by the helper workgroup of this launch
-  const unsigned *zready;  // >= zwant: Z_k (zred) is complete;  tready >= twant: T_k is complete
-  const unsigned *tready;
-  unsigned zwant, twant;
-  unsigned *coreflag;      // set to coretoken once the new behind core is stored (agent scope): the batch-side workgroups extend with it
+  const float *prepRaw;    // raw gradient of this step [h][RW] (beside prepB / prepG), written by the helper workgroups
+  const unsigned *pready;  // >= pwant: every helper workgroup has stored its slice of the three
+  unsigned pwant;
+  double *Apub;            // out: behind core before rounding [D h][m], 1 / sigma [m], next behind norm environment [m][m]
+  unsigned *coreflag;      // set to coretoken once Apub and the float32 behind core are stored: helpers project, batch side extends
   unsigned coretoken;
   unsigned *abort_flag;    // set by any workgroup whose wait timed out; every wait of the launch gives up once it is set
 };
 
 // LDS that survives from one step of a persistent sweep to the next (update workgroup only)
-struct PersistLds { double *Nh, *invs, *Ad; float *A; };
+struct PersistLds { double *Nh, *Ad; };
 __host__ __device__ inline PersistLds persist_lds(unsigned char *base, int Mcap) {
   PersistLds q;
   q.Nh = (double *)base;                       // [m][m]   behind norm environment of the next step
-  q.invs = q.Nh + (size_t)Mcap * Mcap;         // [m]      1 / sigma of the kept columns
-  q.Ad = q.invs + ((Mcap + 1) & ~1);           // [D h][m] behind core of the step just finished (U sqrt(S)) before its rounding to float32:
-                                               //          the projection of T with it divides by sigma, so rounding errors of A' or T
-                                               //          would come back multiplied by sigma_max / sigma_j
-  q.A = (float *)(q.Ad + (size_t)kD * Mcap * Mcap);   // the same as stored (float32): projects the float32 pre-gradient Z
+  q.Ad = q.Nh + (size_t)Mcap * Mcap;           // [D h][m] behind core of the step just finished (U sqrt(S)) before its rounding to float32
   return q;
 }
 inline size_t persist_lds_bytes(int Mcap) {
-  return ((size_t)Mcap * Mcap + ((Mcap + 1) & ~1) + (size_t)kD * Mcap * Mcap) * sizeof(double) + (size_t)kD * Mcap * Mcap * sizeof(float) + 16;
+  return ((size_t)Mcap * Mcap + (size_t)kD * Mcap * Mcap) * sizeof(double) + 16;
 }
 
 struct NormChainSite {

@@ -84,27 +84,28 @@ struct WidePipeParams {
   unsigned *zready;           // set to zpublish once the reduced pre-gradient is stored (agent scope)
   unsigned zpublish;
   unsigned *abort_flag;
+  double *stamps;             // diagnostics (batch-side workgroup 0 of the stamped step): 100 MHz real-time stamps
 };
 
 // Bounded wait of ONE lane until *flag >= want (flags of a persistent sweep only grow).  0: seen, 1: timed out, 2: another workgroup
 // gave up first (abort word set).  Relaxed agent-scope polls; the caller meets its workgroup at a barrier before any load of the
 // handed-off data.
 __device__ inline int spin_wait_ge(const unsigned *flag, unsigned want, const unsigned *abort_flag) {
-  for (int spins = 0; spins < (1 << 22); ++spins) {
+  for (int spins = 0; spins < (1 << 19); ++spins) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return 0;
     if ((spins & 63) == 63 && abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 2;
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(24);                // ~1500 cycles between polls: ~90 workgroups poll the same few words
   }
   return 1;
 }
 
 // the same for two flags at once (both polls in flight together)
 __device__ inline int spin_wait_ge2(const unsigned *f1, unsigned w1, const unsigned *f2, unsigned w2, const unsigned *abort_flag) {
-  for (int spins = 0; spins < (1 << 22); ++spins) {
+  for (int spins = 0; spins < (1 << 19); ++spins) {
     const unsigned a = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a >= w1 && b >= w2) return 0;
     if ((spins & 63) == 63 && abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 2;
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(24);                // ~1500 cycles between polls: ~90 workgroups poll the same few words
   }
   return 1;
 }
@@ -159,26 +160,42 @@ inline int wide_pipe_ztiles(const WidePipeParams &p) {
 // grid = w.wg0 + w.nwide workgroups of 1024 threads (kernels_narrow.hip)
 void launch_step_pipe(const NarrowParams &p, const WidePipeParams &w, size_t lds_bytes, hipStream_t st);
 
-// persistent sweep (kernels_narrow.hip: sweep_persist_kernel): what the helper workgroup needs for T_k, and one record per step
+// persistent sweep (kernels_narrow.hip: sweep_persist_kernel): what a helper workgroup needs for step k, and one record per step
 struct PersistHelperParams {
-  int zr, s, g, L;           // T_k[zr][D][D][g][L] = sum_s W[zr][D][s][L] . A_{k+1}(s, d', g)
-  const float *W;            // B_new(k-1) (contiguous), or nullptr at k == 0: the label core `lab` is W
+  int zr, s, g, L, h;        // rows of T_k (D * behind bond of step k-1; 1 at k == 0), shared / ahead / behind bond of step k
+  int l2_flag;
+  const float *W;            // B_new(k-1) (contiguous [zr][D][s][L]), or nullptr at k == 0: the label core `lab` is W
   CoreView lab, pl;
-  double *T;                 // float64: exact sums of float32 products
+  const double *Ng;          // ahead norm environment of step k (nullptr == 1)
+  double *T, *TN;            // T_k, T_k . Ng   [zr][D][D][g][L] float64
+  const float *Z;            // reduced pre-gradient Z_k [zr][RW]
+  float *prepRaw, *prepB;    // out [h][RW]
+  double *prepG;
+  const double *Apub;        // A' [zr][h], 1 / sigma [h], Nh [h][h] of step k-1 (update workgroup)
   const unsigned *flag;      // >= want: B_new(k-1) is stored (want == 0: nothing to wait for)
   unsigned want;
-  unsigned *tready;          // set to `publish` once T_k is stored
-  unsigned publish;
+  const unsigned *aflag;     // >= awant: Apub is stored (awant == 0 at k == 0: the identity)
+  unsigned awant;
+  const unsigned *zready;    // >= zwant: Z_k is reduced
+  unsigned zwant;
+  unsigned *tcnt, *pcnt;     // arrival counters of this step: part 1 (T slices), part 2 (projections)
   unsigned *abort_flag;
   int *status;
+  double *stamps;            // diagnostics (helper 0 of the stamped step): 100 MHz real-time stamps of part 2
 };
 struct PersistStep { NarrowParams n; WidePipeParams w; PersistHelperParams t; };
-inline size_t persist_helper_lds_bytes(int zr, int s, int g, int L) {
-  const size_t nW = (size_t)zr * kD * s * L, nP = (size_t)s * kD * g, nT = (size_t)zr * kD * kD * g * L;
-  return (((nW + 3) & ~(size_t)3) + ((nP + 3) & ~(size_t)3)) * sizeof(float) + nT * sizeof(double) + 32;
+constexpr int kPersistHelpers = 8;
+inline size_t persist_helper_lds_bytes(int zr, int s, int g, int L, int h, int nH) {
+  const size_t DG = (size_t)kD * g, RW = kD * DG * L;
+  const size_t per = ((size_t)zr * kD + nH - 1) / nH, cw = (RW + nH - 1) / nH;
+  const size_t p1 = (((per * s * L + 3) & ~(size_t)3) + (((size_t)s * DG + 3) & ~(size_t)3)) * sizeof(float) +
+                    ((((size_t)g * g + 1) & ~(size_t)1) + 2 * per * DG * L) * sizeof(double);
+  const size_t p2 = (2 * (size_t)zr * h + ((h + 1) & ~1) + (((size_t)h * h + 1) & ~(size_t)1) + 2 * (size_t)zr * cw + (size_t)h * cw) * sizeof(double) +
+                    (size_t)zr * cw * sizeof(float);
+  return (p1 > p2 ? p1 : p2) + 64;
 }
-void launch_sweep_persist(const PersistStep *steps_dev, const WidePipeParams *pro_dev, int n_steps, int grid, size_t lds_bytes,
-                          hipStream_t st);
+// steps_dev: n_steps + 1 records, the last one carrying the prologue of the batch side in its `w`
+void launch_sweep_persist(const PersistStep *steps_dev, int n_steps, int n_helpers, int grid, size_t lds_bytes, hipStream_t st);
 
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -187,7 +204,7 @@ void launch_sweep_persist(const PersistStep *steps_dev, const WidePipeParams *pr
 // ------------------------------------------------------------------------------------------------------------------
 // returns true when the workgroup gave up (persistent sweep: a wait timed out here or elsewhere)
 template <class WP>
-__device__ inline bool wide_pipe_block(const WP &p, float *smem) {
+__device__ __forceinline__ bool wide_pipe_block(const WP &p, float *smem) {
   const WidePipeDims dm = wide_pipe_dims(p);
   const WidePipeSmem w = wide_pipe_carve(smem, p, dm);
   const int tid = threadIdx.x, NT = kPipeThreads;
@@ -208,6 +225,9 @@ __device__ inline bool wide_pipe_block(const WP &p, float *smem) {
 
   bool flag_seen = !p.wait_flag;
   __shared__ int sGiveUp;
+  double *bst = (p.persist && p.stamps && blockIdx.x == (unsigned)p.wg0 && tid == 0) ? p.stamps : nullptr;
+  auto rt = []() { return (double)(__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1)); };
+  if (bst) bst[32] = rt();
   if (p.persist) {
     // the extension core A_{j-1} is written by the update workgroup of THIS launch (end of its step j-1)
     if (tid == 0) {
@@ -217,6 +237,7 @@ __device__ inline bool wide_pipe_block(const WP &p, float *smem) {
     }
     lds_barrier();
     if (sGiveUp) return true;
+    if (bst) bst[33] = rt();
   }
   for (int tt = 0; tt < p.tiles_per_wg; ++tt) {
     const int tile = wg + tt * p.nwide;
@@ -321,6 +342,7 @@ __device__ inline bool wide_pipe_block(const WP &p, float *smem) {
       }
       lds_barrier();                                            // the poll is over; P', Q', Qn are complete
       if (p.persist && sGiveUp) return true;
+      if (bst && tt == 0) bst[34] = rt();
       const int rowlen = nJ * L;
       if (tt == 0) {                                              // B'[i][(jj, l)] at the odd row stride, zero padded
         if (p.wait_flag && (rowlen & 3) == 0) {
@@ -430,6 +452,7 @@ __device__ inline bool wide_pipe_block(const WP &p, float *smem) {
     }
   }
   if (!p.do_z) return false;
+  if (bst) bst[35] = rt();
 
   // ---- partial tensor of this workgroup -> slab (agent-scope stores), then the two-level fixed-order reduction ----------
   float *slab = p.slabs + (size_t)wg * p.slab_stride;
@@ -469,6 +492,7 @@ __device__ inline bool wide_pipe_block(const WP &p, float *smem) {
   const int g_lo = grp * p.gsz, g_n = min(p.gsz, p.nwide - g_lo);
   if (tid == 0) sTicket = __hip_atomic_fetch_add(p.gcnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   lds_barrier();
+  if (bst) bst[36] = rt();
   if (sTicket != (unsigned)(g_n - 1)) return false;               // not the last arriver of its group
   // The last arriver reads what the other workgroups stored: one agent-scope acquire (invalidates this CU's L1 and the
   // non-coherent lines of its L2), drained, then a barrier, then ordinary 16-byte loads, all of an element's summands
@@ -487,6 +511,7 @@ __device__ inline bool wide_pipe_block(const WP &p, float *smem) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     if (tid == 0) __hip_atomic_store(p.zready, p.zpublish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p.stamps && tid == 0) p.stamps[37] = rt();
   };
   auto sum_slabs = [&](const float *src, int count, float *dst, bool publish) {
     const int n4 = (n + 3) / 4;

@@ -33,4 +33,9 @@ for persistent in (True, False):
     st = ctx.step_debug('scalars')[5:]
     print('%s: cycles pre %.0f / jacobi %.0f / post %.0f ; rounds %.0f ; kernel-or-step us %.1f | pre split: front %.0f (flags seen at %.0f) / B %.0f / L2 %.0f / sums+update %.0f / gram %.0f | post split: sort %.0f / cores %.0f / norm env %.0f'
           % ('persistent' if persistent else 'per-step  ', st[0], st[1], st[2], st[50], st[3] / 100.0, st[9], st[20], st[10], st[11], st[12], st[13], st[6], st[7], st[8]))
+    if persistent:
+        print('   helper 0, part 2 of that step, us relative to the update workgroup starting the step: enter %.2f | core flag seen %.2f | T seen %.2f | Z seen %.2f | operands in LDS %.2f | products issued %.2f | arrived %.2f | update workgroup saw all arrivals %.2f'
+              % tuple((st[i] - st[28]) / 100.0 for i in (22, 23, 30, 24, 25, 26, 27, 29)))
+        print('   batch-side workgroup 0 in the iteration of that step (f of step k, Z of step k+1), same clock: enter %.2f | core flag seen %.2f | B_new flag seen %.2f | tiles done %.2f | partial stored + ticket %.2f | reduced Z published (last arriver) %.2f'
+              % tuple((st[i] - st[28]) / 100.0 for i in (32, 33, 34, 35, 36, 37)))
     ctx.close()
