@@ -151,6 +151,7 @@ def main():
     ap.add_argument('--no-resident', action='store_true', help='skip the secondary single-resident-batch measurement')
     ap.add_argument('--classic', action='store_true', help='classic launch sequence instead of the pipelined single-launch step')
     ap.add_argument('--per-step', action='store_true', help='one launch per sweep step (round 2) instead of the persistent per-sweep launch')
+    ap.add_argument('--persist-mode', type=int, default=None, choices=[1, 2], help='persistent sweep as one kernel (1) or one kernel per role (2); default: the library default')
     ap.add_argument('--pipe-tiles', type=int, default=0, help='sample tiles per batch-side workgroup on steps with a long SVD (tnml_set_step_pipeline(ctx, n), n >= 2)')
     ap.add_argument('--sync-interval', type=int, default=0, help='drain the stream every so many sweep steps (runs under rocprofv3 --pmc)')
     ap.add_argument('--check-launches', action='store_true', help='read the launch status back after every kernel launch')
@@ -180,7 +181,9 @@ def main():
     if args.check_launches:
         ctx.debug_enable(4)
     if args.per_step:
-        ctx.set_persistent(False)
+        ctx.set_persistent(0)
+    elif args.persist_mode:
+        ctx.set_persistent(args.persist_mode)
     if args.classic:
         ctx.set_step_pipeline(False)
     elif args.pipe_tiles >= 2:

@@ -174,7 +174,12 @@ int tnml_set_step_pipeline(tnml_ctx *ctx, int on);
  * default: a persistent kernel whose update workgroup, helper workgroup and batch-side workgroups each loop over the N-1 steps and
  * hand their results to each other through flags in memory.  Sweeps it does not cover (partial sweeps, a
  * communicator, adaptive truncation, per-step capture, merged tensors beyond one workgroup's LDS) take one launch per step as
- * before.  on = 0 forces the per-step launches everywhere. */
+ * before.
+ *   on = 2 (default)  the three roles as three launches on three streams of the context, resident together (each role then has its
+ *                     own register allocation: the fastest form); a tool that SERIALISES launches (rocprofv3 --pmc) keeps them
+ *                     from meeting: the bounded waits then time out and tnml_sweep fails with TNML_ERR_STATE -- use 1 or 0 there
+ *   on = 1            the three roles in ONE launch
+ *   on = 0            one launch per step everywhere */
 int tnml_set_persistent(tnml_ctx *ctx, int on);
 
 /* tnml_sweep enqueues every launch of its n_steps steps without waiting (2 - 14 launches per step).  A profiler that

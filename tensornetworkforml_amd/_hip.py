@@ -336,8 +336,8 @@ class Context:
         _chk(lib().tnml_set_step_pipeline(self._h, int(on)))
 
     def set_persistent(self, on=True):
-        """True (default): a full sweep is ONE persistent launch where it applies; False: one launch per step everywhere."""
-        _chk(lib().tnml_set_persistent(self._h, int(bool(on))))
+        """2 / True-like default: a full sweep as one persistent launch per role; 1: as one launch; 0 / False: one launch per step."""
+        _chk(lib().tnml_set_persistent(self._h, int(on)))
 
     def set_sync_interval(self, n_steps):
         """Drain the stream every n_steps sweep steps (0: never); for runs under a dispatch-intercepting profiler."""

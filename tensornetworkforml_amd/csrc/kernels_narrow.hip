@@ -215,7 +215,7 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
   float *sRaw = k.fBp;                          // raw gradient [h][RW] (float): dead before phase 5 rewrites fBp
   if (p.persist) {
     if (tid == 0) {
-      const int bad = spin_wait_ge(p.pready, p.pwant, p.abort_flag);
+      const int bad = spin_wait_ge(p.pready, p.pwant, p.abort_flag, 1);
       if (bad == 1) { atomicOr(p.status, 4); __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       k.sFlag[3] = bad;
     }
@@ -1047,6 +1047,17 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
            });
   }
   lds_barrier();
+  if (p.persist) {
+    // The next step's projections are formed by the helper workgroups: they get the behind core before its rounding to float32
+    // (the projection divides by sigma: rounding errors of A' would come back multiplied by sigma_max / sigma_j) and 1 / sigma, now,
+    // so that the stores travel while the norm environment is formed; the batch-side workgroups extend their environments with
+    // the float32 core in its slot.  Agent-scope stores; the flag follows at the end of the step.
+    for (int e = tid; e < r * mk; e += NT) __hip_atomic_store(p.Apub + e, PL.Ad[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int sp = tid; sp < mk; sp += NT) {
+      const double iq = k.dSq[ne + sp];
+      __hip_atomic_store(p.Apub + r * mk + sp, iq * iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 
   if (p.stamps && tid == 0) t_c2c = __builtin_amdgcn_s_memtime();
   // ---- phase 10: behind norm environment of the next step ------------------------------------------
@@ -1057,7 +1068,10 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
     }
     // Nh_new[s', s''] = sum_{(h_, d)} Cb[(h_, d), s'] T2[(h_, d), s'']
     mm_lds(1, mk, mk, h * D, k.sCb, 0, 1, mk, k.dT2, 0, mk, 1,
-           [&](int, int i, int j, double v) { p.Nh_new[i * mk + j] = v; if (p.persist) PL.Nh[i * mk + j] = v; });
+           [&](int, int i, int j, double v) {
+             p.Nh_new[i * mk + j] = v;
+             if (p.persist) { PL.Nh[i * mk + j] = v; __hip_atomic_store(p.Apub + r * mk + mk + i * mk + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+           });
   }
 
   if (p.stamps && tid == 0) {
@@ -1081,19 +1095,8 @@ __device__ __forceinline__ bool narrow_body(const NP &p, unsigned char *smem_raw
     if (ldtail(2) != 0.f) atomicOr(p.status, 1);
   }
   if (p.persist) {
-    // The next step's projections are formed by the helper workgroups: they get the behind core before its rounding to float32
-    // (the projection divides by sigma: rounding errors of A' would come back multiplied by sigma_max / sigma_j), 1 / sigma and
-    // the behind norm environment of the next step; the batch-side workgroups extend their environments with the float32 core in
-    // its slot.  Everything leaves with agent-scope stores; every wave drains, the workgroup meets, one lane raises the flag.
-    lds_barrier();                                           // PL.Ad, PL.Nh complete
-    double *pub = p.Apub;                                    // [r * mk] A', [mk] 1 / sigma, [mk * mk] Nh
-    for (int e = tid; e < r * mk; e += NT) __hip_atomic_store(pub + e, PL.Ad[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int sp = tid; sp < mk; sp += NT) {
-      const double iq = k.dSq[ne + sp];
-      __hip_atomic_store(pub + r * mk + sp, iq * iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (p.Nh_new)
-      for (int e = tid; e < mk * mk; e += NT) __hip_atomic_store(pub + r * mk + mk + e, PL.Nh[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the behind core, 1 / sigma and the behind norm environment left for the helper workgroups as their products finished: see
+    // publish_core / the norm-environment product) every storing wave drains, the workgroup meets, one lane raises the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     if (tid == 0) __hip_atomic_store(p.coreflag, p.coretoken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1209,57 +1212,62 @@ __device__ __forceinline__ bool persist_helper_block(const HP &t, int hid, int n
     return false;
   }
   // ---------------- part 2: columns [c0, c0 + nc) of the RW columns ----------------
+  // Order of the waits = order in which the operands become final: T_k / TN_k (beside the previous SVD), Z_k (shortly before or
+  // after the previous step ends), A' / 1 / sigma / Nh (the previous step's last act).  Only the last load and the two products
+  // are on the critical path of the sweep.
   const int cw = (RW + nH - 1) / nH, c0 = min(RW, hid * cw), nc = min(RW, c0 + cw) - c0;
+  const int cw3 = 3 * cw;
   double *sA = (double *)smem_raw;                           // [zr][h]  A' (float64)
-  double *sAf = sA + (size_t)zr * h;                         // [zr][h]  A' as stored (float32 values)
-  double *sIv = sAf + (size_t)zr * h;                        // [h]      1 / sigma
+  double *sIv = sA + (size_t)zr * h;                         // [h]      1 / sigma
   double *sNh = sIv + ((h + 1) & ~1);                        // [h][h]
-  double *sT = sNh + (((size_t)h * h + 1) & ~(size_t)1);     // [zr][cw]
-  double *sN = sT + (size_t)zr * cw;                         // [zr][cw]
-  double *sP2 = sN + (size_t)zr * cw;                        // [h][cw]  diag(1 / sigma) A'^T TN
-  float *sZc = (float *)(sP2 + (size_t)h * cw);              // [zr][cw]
+  double *sS = sNh + (((size_t)h * h + 1) & ~(size_t)1);     // [zr][3 cw]  (Z | T | TN) columns of this slice
+  double *sP2 = sS + (size_t)zr * cw3;                       // [h][cw]  diag(1 / sigma) A'^T TN
+  float *sZf = (float *)(sP2 + (size_t)h * cw);              // [zr][cw] Z columns of this slice
+  float *sAff = sZf + (size_t)zr * cw;                       // [zr][h]  A' as stored (float32)
   double *hst = (t.stamps && hid == 0 && tid == 0) ? t.stamps : nullptr;
   auto rt = []() { return (double)(__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1)); };
-  if (tid == 0) {
-    if (hst) hst[22] = rt();
-    int bad = t.awant ? spin_wait_ge(t.aflag, t.awant, t.abort_flag) : 0;
-    if (hst) hst[23] = rt();
-    if (!bad) bad = spin_wait_ge(t.tcnt, (unsigned)nH, t.abort_flag);
-    if (hst) hst[30] = rt();
-    if (!bad) bad = spin_wait_ge(t.zready, t.zwant, t.abort_flag);
-    if (hst) hst[24] = rt();
-    give_up(bad);
-  }
+  if (tid == 0) { if (hst) hst[22] = rt(); give_up(spin_wait_ge(t.tcnt, (unsigned)nH, t.abort_flag)); if (hst) hst[30] = rt(); }
   lds_barrier();
   if (sBad) return true;
+  for (int e = tid; e < zr * nc; e += NT) {
+    const int i = e / nc, cc = e - i * nc;
+    const size_t src = (size_t)i * RW + c0 + cc;
+    sS[i * cw3 + cw + cc] = __hip_atomic_load(t.T + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sS[i * cw3 + 2 * cw + cc] = t.l2_flag ? __hip_atomic_load(t.TN + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  }
+  lds_barrier();                                             // (tid 0 rewrites sBad)
+  if (tid == 0) { give_up(spin_wait_ge(t.zready, t.zwant, t.abort_flag)); if (hst) hst[24] = rt(); }
+  lds_barrier();
+  if (sBad) return true;
+  for (int e = tid; e < zr * nc; e += NT) {
+    const int i = e / nc, cc = e - i * nc;
+    sZf[i * cw + cc] = ld_sc1(t.Z + (size_t)i * RW + c0 + cc);
+  }
+  lds_barrier();
+  if (tid == 0) { give_up(t.awant ? spin_wait_ge(t.aflag, t.awant, t.abort_flag) : 0); if (hst) hst[23] = rt(); }
+  lds_barrier();
+  if (sBad) return true;
+  if (t.awant) {
+    const double *pub = t.Apub;
+    for (int e = tid; e < zr * h; e += NT) { const double a = __hip_atomic_load(pub + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sA[e] = a; sAff[e] = (float)a; }
+    for (int e = tid; e < h; e += NT) sIv[e] = __hip_atomic_load(pub + zr * h + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t.l2_flag) for (int e = tid; e < h * h; e += NT) sNh[e] = __hip_atomic_load(pub + zr * h + h + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (tid == 0) {                                     // k == 0: zr == h == 1, the identity
+    sA[0] = 1.0; sAff[0] = 1.f; sIv[0] = 1.0; sNh[0] = 1.0;
+  }
+  lds_barrier();
+  if (hst) hst[25] = rt();
   if (nc > 0) {
-    if (t.awant) {
-      const double *pub = t.Apub;
-      for (int e = tid; e < zr * h; e += NT) {
-        const double a = __hip_atomic_load(pub + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sA[e] = a; sAf[e] = (double)(float)a;
-      }
-      for (int e = tid; e < h; e += NT) sIv[e] = __hip_atomic_load(pub + zr * h + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t.l2_flag) for (int e = tid; e < h * h; e += NT) sNh[e] = __hip_atomic_load(pub + zr * h + h + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (tid == 0) {                                   // k == 0: zr == h == 1, the identity
-      sA[0] = 1.0; sAf[0] = 1.0; sIv[0] = 1.0; sNh[0] = 1.0;
-    }
-    for (int e = tid; e < zr * nc; e += NT) {
-      const int i = e / nc, cc = e - i * nc;
-      const size_t src = (size_t)i * RW + c0 + cc;
-      sT[i * cw + cc] = __hip_atomic_load(t.T + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t.l2_flag) sN[i * cw + cc] = __hip_atomic_load(t.TN + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sZc[i * cw + cc] = ld_sc1(t.Z + src);
-    }
-    lds_barrier();
-    if (hst) hst[25] = rt();
-    // three independent products [h][nc] = A'^T [zr][nc], tiles dealt as one list
-    int slot = mm_lds(1, h, nc, zr, sAf, 0, 1, h, sZc, 0, cw, 1,
-                      [&](int, int i, int j, double v) { st_sc1(t.prepRaw + (size_t)i * RW + c0 + j, (float)v); });
-    slot = mm_lds(1, h, nc, zr, sA, 0, 1, h, sT, 0, cw, 1,
-                  [&](int, int i, int j, double v) { st_sc1(t.prepB + (size_t)i * RW + c0 + j, (float)(v * sIv[i])); }, false, slot);
+    // [h][cw] = Af^T Z with the core as stored, on the float32 matrix pipe (the per-step path's contraction, number for number), and
+    // [h][2 cw] = A'^T (T | TN) with the unrounded core; independent, their tiles dealt as one list
+    mm_lds_f32(h, nc, zr, sAff, 1, h, sZf, cw, 1, [&](int i, int j, float v) { st_sc1(t.prepRaw + (size_t)i * RW + c0 + j, v); });
+    const int slot = (((h + 15) >> 4) * ((nc + 15) >> 4)) & ((NT >> 6) - 1);
+    mm_lds(1, h, t.l2_flag ? 2 * cw : cw, zr, sA, 0, 1, h, sS + cw, 0, cw3, 1,
+           [&](int, int i, int j, double v) {
+             if (j < cw) { if (j < nc) st_sc1(t.prepB + (size_t)i * RW + c0 + j, (float)(v * sIv[i])); }
+             else sP2[i * cw + (j - cw)] = v * sIv[i];
+           }, false, slot);
     if (t.l2_flag) {
-      mm_lds(1, h, nc, zr, sA, 0, 1, h, sN, 0, cw, 1, [&](int, int i, int j, double v) { sP2[i * cw + j] = v * sIv[i]; }, false, slot);
       lds_barrier();
       // (Ln.B.Rn)[e_, c] = sum_a Nh[a, e_] P2[a, c]
       mm_lds(1, h, nc, h, sNh, 0, 1, h, sP2, 0, cw, 1,
@@ -1274,34 +1282,95 @@ __device__ __forceinline__ bool persist_helper_block(const HP &t, int hid, int n
   return false;
 }
 
-typedef const __attribute__((address_space(4))) PersistStep ConstPersistStep;
 __global__ __launch_bounds__(kNarrowThreads) void sweep_persist_kernel(const PersistStep *__restrict__ steps_g, int n_steps, int nH) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // the host wrote the records before the launch and nothing in the kernel writes them: constant address space -> scalar loads
-  ConstPersistStep *steps = (ConstPersistStep *)steps_g;         // [n_steps + 1]: the last record carries the prologue of the batch side
+  // Every role works on a by-value copy of its record for the step (scalar registers, as the per-step kernels' arguments): fields
+  // read on demand from memory would put scalar-load latencies into the inner loops.
   const int blk = blockIdx.x;
   if (blk == 0) {
-    for (int k = 0; k < n_steps; ++k)
-      if (narrow_body(steps[k].n, smem_raw)) break;
+#pragma nounroll
+    for (int k = 0; k < n_steps; ++k) {
+      NarrowParams n;
+      __builtin_memcpy(&n, &steps_g[k].n, sizeof n);
+      if (narrow_body(n, smem_raw)) break;
+    }
   } else if (blk <= nH) {
     // T_0; then per step: the projections of step k, and T_{k+1} once B_new(k) is there -- one call site (the body is inlined once)
 #pragma nounroll
     for (int ph = 0; ph < 2 * n_steps; ++ph) {
+      PersistHelperParams t;
+      __builtin_memcpy(&t, &steps_g[ph >> 1].t, sizeof t);
       lds_barrier();
-      if (persist_helper_block(steps[ph >> 1].t, blk - 1, nH, smem_raw, (ph & 1) != 0)) break;
+      if (persist_helper_block(t, blk - 1, nH, smem_raw, (ph & 1) != 0)) break;
     }
   } else {
     // Z_0 from forward's f (record n_steps), then one iteration per step -- one call site
 #pragma nounroll
     for (int it = 0; it <= n_steps; ++it) {
+      WidePipeParams w;
+      __builtin_memcpy(&w, &steps_g[it == 0 ? n_steps : it - 1].w, sizeof w);
       lds_barrier();                                       // the previous iteration's LDS arrays are dead
-      if (wide_pipe_block(steps[it == 0 ? n_steps : it - 1].w, (float *)smem_raw)) break;
+      if (wide_pipe_block(w, (float *)smem_raw)) break;
     }
   }
 }
 
 void launch_sweep_persist(const PersistStep *steps_dev, int n_steps, int n_helpers, int grid, size_t lds_bytes, hipStream_t st) {
   hipLaunchKernelGGL(sweep_persist_kernel, dim3(grid), dim3(kNarrowThreads), lds_bytes, st, steps_dev, n_steps, n_helpers);
+}
+
+// The same sweep as THREE launches, one per role, on three streams: the roles then get their own register allocation (inside one
+// kernel the batch-side loops spill and lose their unrolling to the update workgroup's code, and run ~2.4x slower than in the
+// per-step kernel).  The three grids communicate through the same flags; they need to be resident together, which holds when
+// nothing serialises launches (88 workgroups on a 256-CU device) -- a dispatch-serialising profiler (rocprofv3 --pmc) makes the first
+// grid wait in vain: its bounded polls time out and the sweep fails with TNML_ERR_STATE; use tnml_set_persistent(ctx, 1) (one
+// kernel) or 0 (per-step launches) there.
+__global__ __launch_bounds__(kNarrowThreads) void persist_update_kernel(const PersistStep *__restrict__ steps_g, int n_steps, int rec_off) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // The record of step k+1 is fetched into LDS while step k runs (two waves, at the start of the step) and becomes the by-value
+  // argument of the next narrow_body from there: a fetch from memory between two steps is ~1.6 us on the critical path.
+  constexpr int kWords = (int)(sizeof(NarrowParams) / sizeof(unsigned));
+  static_assert(sizeof(NarrowParams) % sizeof(unsigned) == 0, "NarrowParams is copied word by word");
+  unsigned *rec = reinterpret_cast<unsigned *>(smem_raw + rec_off);
+  for (int e = threadIdx.x; e < kWords; e += kNarrowThreads) rec[e] = reinterpret_cast<const unsigned *>(&steps_g[0].n)[e];
+  lds_barrier();
+#pragma nounroll
+  for (int k = 0; k < n_steps; ++k) {
+    NarrowParams n;
+    __builtin_memcpy(&n, rec, sizeof n);
+    lds_barrier();                                         // everybody holds its copy: the buffer may take the next record
+    if (k + 1 < n_steps)
+      for (int e = threadIdx.x; e < kWords; e += kNarrowThreads) rec[e] = reinterpret_cast<const unsigned *>(&steps_g[k + 1].n)[e];
+    if (narrow_body(n, smem_raw)) break;
+  }
+}
+__global__ __launch_bounds__(kNarrowThreads) void persist_helper_kernel(const PersistStep *__restrict__ steps_g, int n_steps, int nH) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#pragma nounroll
+  for (int ph = 0; ph < 2 * n_steps; ++ph) {
+    PersistHelperParams t;
+    __builtin_memcpy(&t, &steps_g[ph >> 1].t, sizeof t);
+    lds_barrier();
+    if (persist_helper_block(t, (int)blockIdx.x, nH, smem_raw, (ph & 1) != 0)) break;
+  }
+}
+__global__ __launch_bounds__(kNarrowThreads) void persist_batch_kernel(const PersistStep *__restrict__ steps_g, int n_steps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#pragma nounroll
+  for (int it = 0; it <= n_steps; ++it) {
+    WidePipeParams w;
+    __builtin_memcpy(&w, &steps_g[it == 0 ? n_steps : it - 1].w, sizeof w);
+    w.wg0 = 0;                                             // this grid holds batch-side workgroups only
+    lds_barrier();
+    if (wide_pipe_block(w, (float *)smem_raw)) break;
+  }
+}
+void launch_sweep_persist_split(const PersistStep *steps_dev, int n_steps, int n_helpers, int n_wide, size_t lds_update, size_t lds_helper,
+                                size_t lds_wide, int rec_off, hipStream_t st_update, hipStream_t st_helper, hipStream_t st_wide) {
+  hipLaunchKernelGGL(persist_batch_kernel, dim3(n_wide), dim3(kNarrowThreads), lds_wide, st_wide, steps_dev, n_steps);
+  hipLaunchKernelGGL(persist_helper_kernel, dim3(n_helpers), dim3(kNarrowThreads), lds_helper, st_helper, steps_dev, n_steps, n_helpers);
+  hipLaunchKernelGGL(persist_update_kernel, dim3(1), dim3(kNarrowThreads), lds_update, st_update, steps_dev, n_steps, rec_off);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -48,7 +48,10 @@ struct tnml_ctx {
   int b = 0, b_pad = 0, b_cap = 0;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;             // large-tensor steps: merged tensor and Nh^T.B beside the batch kernel
+  hipStream_t stream2 = nullptr;             // large-tensor steps: merged tensor and Nh^T.B beside the batch kernel; persistent sweep: helper grid
+  hipStream_t stream3 = nullptr;             // persistent sweep in three launches: batch-side grid
+  hipEvent_t ev_p0 = nullptr, ev_p2 = nullptr, ev_p3 = nullptr;
+  int persist_mode = 2;                      // tnml_set_persistent: 0 per-step launches, 1 one kernel per sweep, 2 one kernel per role (default)
   hipEvent_t ev_main = nullptr, ev_prep = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
   // host bookkeeping
@@ -216,6 +219,10 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   c->bond.assign(N - 1, 1);
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_p0, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_p2, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_p3, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
@@ -297,6 +304,10 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->pev1) (void)hipEventDestroy(c->pev1);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
   if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+  if (c->ev_p0) (void)hipEventDestroy(c->ev_p0);
+  if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
+  if (c->ev_p3) (void)hipEventDestroy(c->ev_p3);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -908,7 +919,11 @@ static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float
   WidePipeParams &pro = st[n_steps].w;                       // the batch side's prologue rides in the record after the last step
   double *nbeh = left_dir ? c->Rn : c->Ln, *nahe = left_dir ? c->Ln : c->Rn;
   const int ntiles = c->b_pad / kTS;
-  const int tpw = ntiles >= 64 ? std::max(c->pipe_tpw, c->pipe_tiles) : c->pipe_tpw;
+  // one sample tile per batch-side workgroup while the device has the CUs (the reduced pre-gradient of step k+1 has to be there
+  // when step k ends: with two tiles per workgroup it arrived ~2 us late behind a 40-round SVD); fixed for the whole launch --
+  // a workgroup keeps its samples from step to step
+  int tpw = c->pipe_tpw;
+  while ((ntiles + tpw - 1) / tpw + 1 + kPersistHelpers > c->num_cus) ++tpw;
   const int nwide = (ntiles + tpw - 1) / tpw;
   const int nH = kPersistHelpers;
   if (1 + nH + nwide > c->num_cus) return 0;                 // every workgroup of the launch must be resident
@@ -1023,8 +1038,8 @@ static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float
     flops += 4.0 * c->b * D * D * h * g * L + 2.0 * c->b * D * h * h;
     if (!c->stamps || k <= n_steps / 2) { c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir; }
   }
-  const size_t lds = std::max(std::max(lds_narrow + pbytes, lds_wide), lds_help);
-  if (lds > 160 * 1024) return give_up();
+  const size_t lds = c->persist_mode >= 2 ? lds_narrow + pbytes : std::max(std::max(lds_narrow + pbytes, lds_wide), lds_help);
+  if (lds > 160 * 1024 || lds_wide > 160 * 1024 || lds_help > 160 * 1024) return give_up();
   const int persist_off = (int)((lds - pbytes) & ~(size_t)15);
   for (int k = 0; k < n_steps; ++k) st[k].n.persist_off = persist_off;
   // ---- enqueue: records, zeroed flags and counters, one launch
@@ -1033,8 +1048,25 @@ static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float
   c->pst_cur ^= 1;
   HIP_TRY(hipMemsetAsync(c->pst_flags, 0, 8 * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->pst_cnt, 0, (size_t)(n_steps + 1) * 32 * sizeof(unsigned), c->stream));
-  launch_sweep_persist(c->pst_dev, n_steps, nH, 1 + nH + nwide, lds, c->stream);
-  HIP_TRY(hipGetLastError());
+  if (c->persist_mode >= 2) {
+    // one launch per role: the helper and batch-side grids start once the records and zeroed flags are in place, and the
+    // context's stream continues only after all three have ended
+    HIP_TRY(hipEventRecord(c->ev_p0, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_p0, 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_p0, 0));
+    // (the update grid keeps the next step's record in LDS behind the persistent region)
+    const size_t rec_bytes = (sizeof(NarrowParams) + 15) & ~(size_t)15;
+    if (lds + rec_bytes > 160 * 1024) return give_up();
+    launch_sweep_persist_split(c->pst_dev, n_steps, nH, nwide, lds + rec_bytes, lds_help, lds_wide, (int)lds, c->stream, c->stream2, c->stream3);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_p2, c->stream2));
+    HIP_TRY(hipEventRecord(c->ev_p3, c->stream3));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_p2, 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_p3, 0));
+  } else {
+    launch_sweep_persist(c->pst_dev, n_steps, nH, 1 + nH + nwide, lds, c->stream);
+    HIP_TRY(hipGetLastError());
+  }
   c->prev_left_dir = left_dir;
   c->cnt_steps += n_steps; c->cnt_bytes += bytes; c->cnt_flops += flops;
   c->sweep_launches += 1; c->step_launches += n_steps; c->persist_sweeps += 1;
@@ -1563,7 +1595,9 @@ extern "C" int tnml_set_step_pipeline(tnml_ctx *c, int on) {
 
 extern "C" int tnml_set_persistent(tnml_ctx *c, int on) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  if (on < 0 || on > 2) return fail(TNML_ERR_ARG, "mode %d outside [0, 2]", on);
   c->persist_enabled = on != 0;
+  if (on) c->persist_mode = on;
   return TNML_OK;
 }
 

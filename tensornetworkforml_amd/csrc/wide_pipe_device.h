@@ -90,11 +90,12 @@ struct WidePipeParams {
 // Bounded wait of ONE lane until *flag >= want (flags of a persistent sweep only grow).  0: seen, 1: timed out, 2: another workgroup
 // gave up first (abort word set).  Relaxed agent-scope polls; the caller meets its workgroup at a barrier before any load of the
 // handed-off data.
-__device__ inline int spin_wait_ge(const unsigned *flag, unsigned want, const unsigned *abort_flag) {
+__device__ inline int spin_wait_ge(const unsigned *flag, unsigned want, const unsigned *abort_flag, int tight = 0) {
   for (int spins = 0; spins < (1 << 19); ++spins) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return 0;
     if ((spins & 63) == 63 && abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 2;
-    __builtin_amdgcn_s_sleep(24);                // ~1500 cycles between polls: ~90 workgroups poll the same few words
+    if (tight) __builtin_amdgcn_s_sleep(1);      // the only poller of this word
+    else __builtin_amdgcn_s_sleep(24);           // ~1500 cycles between polls: ~90 workgroups poll the same few words
   }
   return 1;
 }
@@ -190,12 +191,15 @@ inline size_t persist_helper_lds_bytes(int zr, int s, int g, int L, int h, int n
   const size_t per = ((size_t)zr * kD + nH - 1) / nH, cw = (RW + nH - 1) / nH;
   const size_t p1 = (((per * s * L + 3) & ~(size_t)3) + (((size_t)s * DG + 3) & ~(size_t)3)) * sizeof(float) +
                     ((((size_t)g * g + 1) & ~(size_t)1) + 2 * per * DG * L) * sizeof(double);
-  const size_t p2 = (2 * (size_t)zr * h + ((h + 1) & ~1) + (((size_t)h * h + 1) & ~(size_t)1) + 2 * (size_t)zr * cw + (size_t)h * cw) * sizeof(double) +
-                    (size_t)zr * cw * sizeof(float);
+  const size_t p2 = ((size_t)zr * h + ((h + 1) & ~1) + (((size_t)h * h + 1) & ~(size_t)1) + 3 * (size_t)zr * cw + (size_t)h * cw) * sizeof(double) +
+                    ((size_t)zr * cw + (size_t)zr * h) * sizeof(float);
   return (p1 > p2 ? p1 : p2) + 64;
 }
 // steps_dev: n_steps + 1 records, the last one carrying the prologue of the batch side in its `w`
 void launch_sweep_persist(const PersistStep *steps_dev, int n_steps, int n_helpers, int grid, size_t lds_bytes, hipStream_t st);
+// one launch per role on three streams (kernels_narrow.hip)
+void launch_sweep_persist_split(const PersistStep *steps_dev, int n_steps, int n_helpers, int n_wide, size_t lds_update, size_t lds_helper,
+                                size_t lds_wide, int rec_off, hipStream_t st_update, hipStream_t st_helper, hipStream_t st_wide);
 
 
 // ------------------------------------------------------------------------------------------------------------------
