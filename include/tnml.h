@@ -175,10 +175,10 @@ int tnml_set_step_pipeline(tnml_ctx *ctx, int on);
  * hand their results to each other through flags in memory.  Sweeps it does not cover (partial sweeps, a
  * communicator, adaptive truncation, per-step capture, merged tensors beyond one workgroup's LDS) take one launch per step as
  * before.
- *   on = 2 (default)  the three roles as three launches on three streams of the context, resident together (each role then has its
- *                     own register allocation: the fastest form); a tool that SERIALISES launches (rocprofv3 --pmc) keeps them
- *                     from meeting: the bounded waits then time out and tnml_sweep fails with TNML_ERR_STATE -- use 1 or 0 there
- *   on = 1            the three roles in ONE launch
+ *   on = 1 (default)  the three roles in ONE launch
+ *   on = 2            the three roles as three launches on three streams of the context, resident together (each role with its own
+ *                     register allocation; measured equal to on = 1 within 2 %); a tool that SERIALISES launches (rocprofv3 --pmc)
+ *                     keeps them from meeting: the bounded waits then time out and tnml_sweep fails with TNML_ERR_STATE
  *   on = 0            one launch per step everywhere */
 int tnml_set_persistent(tnml_ctx *ctx, int on);
 

@@ -336,7 +336,7 @@ class Context:
         _chk(lib().tnml_set_step_pipeline(self._h, int(on)))
 
     def set_persistent(self, on=True):
-        """2 / True-like default: a full sweep as one persistent launch per role; 1: as one launch; 0 / False: one launch per step."""
+        """1 / True (default): a full sweep as ONE persistent launch; 2: one launch per role on three streams; 0 / False: one launch per step."""
         _chk(lib().tnml_set_persistent(self._h, int(on)))
 
     def set_sync_interval(self, n_steps):

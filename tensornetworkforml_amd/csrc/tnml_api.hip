@@ -51,7 +51,7 @@ struct tnml_ctx {
   hipStream_t stream2 = nullptr;             // large-tensor steps: merged tensor and Nh^T.B beside the batch kernel; persistent sweep: helper grid
   hipStream_t stream3 = nullptr;             // persistent sweep in three launches: batch-side grid
   hipEvent_t ev_p0 = nullptr, ev_p2 = nullptr, ev_p3 = nullptr;
-  int persist_mode = 2;                      // tnml_set_persistent: 0 per-step launches, 1 one kernel per sweep, 2 one kernel per role (default)
+  int persist_mode = 1;                      // tnml_set_persistent: 0 per-step launches, 1 one kernel per sweep (default), 2 one kernel per role
   hipEvent_t ev_main = nullptr, ev_prep = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
   // host bookkeeping

@@ -233,6 +233,7 @@ def test_rccl_path_single_rank(monkeypatch):
     for force in ('0', '1'):
         monkeypatch.setenv('TNML_FORCE_COMM', force)
         ctx = make_ctx(N, D, L, M, gu.indexed(d, 'init_core', N), 0, d['X'], d['y'])
+        ctx.set_persistent(0)        # a communicator takes one launch per step: the same launches on the other side, bit for bit
         tdist.attach_comm(ctx, 0, 1)
         lmax = ctx.forward_logabsmax()
         ctx.forward()
@@ -438,7 +439,7 @@ def test_persistent_sweep_matches_per_step_launches_and_oracle(policy, M, N, b, 
     st = mo.MPSState(N, D, L, M, [c.astype(np.float64) for c in cores32])
     kw = dict(lr=1e-2, weight_dec=1e-3, L2_flag=True, act_fn='softmax', loss_fn='full_cross_ent', T=0.1, trunc=policy)
     ctxs = []
-    for persistent in (True, False):
+    for persistent in (1, 0, 2):             # one kernel per sweep (default), one launch per step, one kernel per role
         ctx = make_ctx(N, D, L, M, cores32, 0, X, y)
         ctx.set_persistent(persistent)
         ctx.profile_reset()
@@ -464,8 +465,10 @@ def test_persistent_sweep_matches_per_step_launches_and_oracle(policy, M, N, b, 
         assert relerr(res[0][1], res[1][1]) < (2e-5 if sw == 0 else 5e-3), sw      # observed 1e-6 / 2e-3 (both amplify the oracle's 2.6e-3)
         assert np.abs(res[0][0][:, 0] - res[1][0][:, 0]).max() <= 1.0 / b + 1e-6
         assert np.abs(res[0][0][:, 1] - res[1][0][:, 1]).max() < 2e-4
+        np.testing.assert_array_equal(res[0][1], res[2][1])       # the same arithmetic in one kernel or three
+        np.testing.assert_array_equal(res[0][0], res[2][0])
     # the persistent context made one launch per sweep, the other one N - 1 (+ the launch that starts a sweep)
-    assert ctxs[0].counters()['launches'] == 2 and ctxs[0].counters()['sweep_steps'] == 2 * (N - 1)
+    assert ctxs[0].counters()['launches'] == 2 and ctxs[0].counters()['sweep_steps'] == 2 * (N - 1) and ctxs[2].counters()['launches'] == 2
     assert ctxs[1].counters()['launches'] >= 2 * (N - 1)
     p2 = rng.random((b, N))
     X2 = np.stack([np.sin(np.pi * p2 / 2), np.cos(np.pi * p2 / 2)], -1).astype(np.float32)
