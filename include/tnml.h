@@ -197,6 +197,11 @@ int tnml_set_sync_interval(tnml_ctx *ctx, int n_steps);
  * choice. */
 int tnml_set_narrow_path(tnml_ctx *ctx, int force_large);
 
+/* The forward environment chain (Network.forward, Network_class.py:227-255) runs on the matrix cores for bond dimensions
+ * <= 32 (one wave per 16 samples) and as plain FMAs otherwise and in the renormalising calibration pass.  force_plain = 1
+ * sends every chain down the plain-FMA kernel (tests, diagnostics); 0 restores the automatic choice. */
+int tnml_set_chain_path(tnml_ctx *ctx, int force_plain);
+
 /* TNML_TRUNC_ADAPTIVE (not reference behaviour): tensor_svd computes the cumulative share of the singular
  * values and the first index where it exceeds `threshold` (Network_class.py:889-891, default argument
  * 0.999) but never uses it.  Under this policy the kept rank is min(M, index + 1), decided on the device

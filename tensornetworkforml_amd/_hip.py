@@ -28,7 +28,7 @@ SYMBOLS = [
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
     'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict', 'tnml_set_trunc_threshold',
     'tnml_set_sync_interval', 'tnml_set_step_pipeline', 'tnml_stage_batch', 'tnml_select_batch', 'tnml_get_counters',
-    'tnml_svd_stats_ex', 'tnml_set_persistent',
+    'tnml_svd_stats_ex', 'tnml_set_persistent', 'tnml_set_chain_path',
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
         L.tnml_l2_term.argtypes = [vp, f32p, C.c_int, C.c_float, f64p, f64p, C.c_size_t]
         L.tnml_set_svd_stop.argtypes = [vp, C.c_double]
         L.tnml_set_narrow_path.argtypes = [vp, C.c_int]
+        L.tnml_set_chain_path.argtypes = [vp, C.c_int]
         L.tnml_predict.argtypes = [vp, f32p, C.c_int, f32p]
         L.tnml_set_trunc_threshold.argtypes = [vp, C.c_double]
         L.tnml_set_sync_interval.argtypes = [vp, C.c_int]
@@ -342,6 +343,10 @@ class Context:
     def set_sync_interval(self, n_steps):
         """Drain the stream every n_steps sweep steps (0: never); for runs under a dispatch-intercepting profiler."""
         _chk(lib().tnml_set_sync_interval(self._h, int(n_steps)))
+
+    def set_chain_path(self, force_plain):
+        """Forward chain as plain FMAs (True) instead of the matrix-core kernel (tests, diagnostics)."""
+        _chk(lib().tnml_set_chain_path(self._h, int(bool(force_plain))))
 
     def set_narrow_path(self, force_large):
         """True: every step takes the large-tensor (HBM-resident) path; False: automatic."""

@@ -47,6 +47,7 @@ void launch_transpose_input(const float *X_bnd, float *X_nbd, int b, int b_pad, 
 // One workgroup owns 16 samples and walks all sites; the core of the current site is staged in
 // LDS, the running environment ping-pongs between two LDS buffers and is streamed to HBM once.
 // ------------------------------------------------------------------------------------------
+typedef float fvec4 __attribute__((ext_vector_type(4)));
 constexpr int kChainTS = 16;
 constexpr int kChainThreads = 512;
 
@@ -156,14 +157,213 @@ __global__ __launch_bounds__(kChainThreads) void env_chain_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same chain on the matrix cores (round 3), for bonds <= 32: ONE WAVE owns 16 samples and walks all sites alone -- no
+// workgroup barrier anywhere.  Per site
+//     env_out[s][o] = sum_{(in, d)} (env_in[s][in] x[s][d]) A[(in, d)][o]                    v_mfma_f32_16x16x4_f32
+// with the samples as rows: A-operand lane (s = lane & 15, q = lane >> 4) holds, for k-step ks, row index (in, d) = 4 ks + q, i.e.
+// in = 2 ks + (q >> 1), d = q & 1 -- the lane keeps its environment values env[s][2 ks + (q >> 1)] in registers and multiplies them by
+// its ONE feature value x[s][q & 1].
+//   * The plain-FMA kernel above spends its 1.8 us per site waiting for memory: every workgroup of the chip needs the same core at
+//     the same time, and the features x[site][sample] of consecutive sites lie 40 KB apart.  Here a lane requests its feature
+//     values of EIGHT sites at once, eight sites ahead; the cores of the block of eight sites two blocks ahead are touched (one
+//     dword per 128-byte line, result folded into a value nobody reads) so that they sit in this XCD's L2 when they are wanted.
+//   * The core of site i + 1 (<= 8 KB) is requested as it lies in memory (16-byte loads, <= 8 per lane) before site i is computed
+//     and written to the other half of a double-buffered LDS area after it; the B operands are LDS reads through the core's strides.
+//   * The result tile (rows = samples 4 q + reg, column o = lane & 15) leaves as ONE 16-byte store per lane and column tile (four
+//     consecutive samples of bond index o: the environment stack is [bond][sample]) and is turned into the next site's A-operand
+//     layout through a 2 KB LDS tile (written and read by the same wave: in order, no barrier).
+// The plain-FMA kernel remains for bonds > 32 and for the renormalising calibration pass.
+// ------------------------------------------------------------------------------------------
+constexpr int kChainMaxKS = 16;         // k-steps of 4: n_in <= 32
+constexpr int kChainLD = 36;            // row stride of the wave's result tile (16-byte reads along a row of bond indices)
+constexpr int kChainCoreMax = 32 * kD * 32;
+constexpr int kChainBlock = 8;          // sites per feature request
+// NV4 = 16-byte loads per lane that cover the largest core of the chain (host: 1, 2, 4 or 8); every site issues all of them
+// (clamped addresses), so that the staging registers never become a stack array.
+//
+// The vector-memory counter of gfx950 retires IN ORDER: a wait for the core requested one site ago is also a wait for everything
+// requested before it.  A far-ahead request issued by the computing wave itself (features eight sites ahead, cache warming) would
+// therefore put the latency of HBM on the very next wait.  So the far-ahead requests belong to a SECOND wave of the workgroup that
+// computes nothing: it touches one dword of every 128-byte line the computing wave will want (cores and this workgroup's
+// features) a few blocks of eight sites ahead of it, paced by a progress word in LDS, and the computing wave's own requests -- one
+// site ahead -- find their data in the L2 of the XCD.
+#ifdef TNML_CHAIN_STAMPS
+__device__ unsigned long long g_chain_stamps[16];
+#define TNML_STAMP(k) { __builtin_amdgcn_sched_barrier(0); if (i == 400 && blockIdx.x == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_[k] = __builtin_amdgcn_s_memtime(); } __builtin_amdgcn_sched_barrier(0); }
+#define TNML_STAMP_OUT() if (i == 401 && blockIdx.x == 7 && lane == 0) { for (int k = 0; k < 7; ++k) g_chain_stamps[k] = st_[k]; g_chain_stamps[7] = __builtin_amdgcn_s_memtime(); }
+#else
+#define TNML_STAMP(k)
+#define TNML_STAMP_OUT()
+#endif
+// NKS = k-steps of 4 rows (in, d) every site runs (covers the largest bond; av is zero beyond a site's own n_in), NT = column tiles
+template <int NV4, int NT, int NKS>
+__global__ __launch_bounds__(128) void env_chain_mfma_kernel(const ChainSite *__restrict__ sites, int n_sites, const float *__restrict__ cores,
+                                                             const float *__restrict__ labcore, const float *__restrict__ X,
+                                                             float *__restrict__ env_base, float *__restrict__ f, int b_pad) {
+  __shared__ __attribute__((aligned(16))) float sC[2][kChainCoreMax];
+  __shared__ __attribute__((aligned(16))) float sE[16 * kChainLD];
+  __shared__ int sProg;
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int s0 = blockIdx.x * 16;
+  if (threadIdx.x >= 64) {
+    // ---- the warming wave ----
+    float warm = 0.f;
+    for (int i0 = 0; i0 < n_sites; i0 += kChainBlock) {
+      for (int spin = 0; spin < (1 << 16); ++spin) {
+        if (i0 <= __hip_atomic_load(&sProg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 3 * kChainBlock) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+      float w[kChainBlock + 1];
+      // features: the 16 samples of this workgroup are one 128-byte line per site
+      w[kChainBlock] = X[((size_t)sites[min(i0 + (lane & (kChainBlock - 1)), n_sites - 1)].x_site * b_pad + s0) * kD];
+#pragma unroll
+      for (int j = 0; j < kChainBlock; ++j) {
+        const ChainSite &c = sites[min(i0 + j, n_sites - 1)];
+        w[j] = (c.is_label ? labcore : cores)[c.core_off + min(lane * 32, c.n_in * kD * c.n_out - 1)];
+      }
+#pragma unroll
+      for (int j = 0; j <= kChainBlock; ++j) warm += w[j];
+    }
+    if (n_sites < 0) f[lane] = warm;      // never taken: keeps the loads alive
+    return;
+  }
+  // ---- the computing wave ----
+  // Everything a site needs is in registers when the site starts: its A operands av[ks] = env[s = r][in = 2 ks + half] x[s][dsel]
+  // and its B operands bv[t][ks] = A[(in, dsel)][o = 16 t + r] were read from LDS at the end of the previous site.  Rows of the
+  // last k-step that lie beyond n_in meet av == 0 (columns beyond n_out are written to the hand-over tile as zeros) and finite
+  // B values (the LDS area is zero-filled at the start and only ever holds core elements), so nothing has to be masked there.
+  // A single wave has nobody to hide its VALU instructions behind, so the site loop keeps them few: the LDS offsets of the B
+  // operands depend on the core's strides only and are kept in registers until a site with other strides comes (chain ends); the
+  // loop is unrolled by two so that the LDS half a site reads is an immediate offset.
+  const int half = q >> 1, dsel = q & 1;
+  for (int e = lane; e < 2 * kChainCoreMax; e += 64) sC[0][e] = 0.f;
+  for (int e = lane; e < 16 * kChainLD; e += 64) sE[e] = 0.f;
+  fvec4 pre[NV4];                         // the core of the NEXT site on its way from memory to LDS
+#define TNML_CORE_LOAD(c)                                                                                          \
+  {                                                                                                                \
+    const fvec4 *src_ = reinterpret_cast<const fvec4 *>(((c).is_label ? labcore : cores) + (c).core_off);          \
+    const int n4_ = ((c).n_in * kD * (c).n_out + 3) >> 2;                                                          \
+    _Pragma("unroll") for (int u = 0; u < NV4; ++u) pre[u] = src_[min(lane + 64 * u, n4_ - 1)];                    \
+  }
+#define TNML_CORE_PUT(dst)                                                                                         \
+  _Pragma("unroll") for (int u = 0; u < NV4; ++u) reinterpret_cast<fvec4 *>(dst)[lane + 64 * u] = pre[u];
+#define TNML_X_AT(c) X[((size_t)(c).x_site * b_pad + s0 + r) * kD + dsel]
+  int boff[NT][NKS];              // LDS offsets (bytes, within a half) of this lane's B operands
+#define TNML_B_OFFSETS(c)                                                                                          \
+  {                                                                                                                \
+    const int base_ = dsel * (c).s_d + half * (c).s_in, step_ = 2 * (c).s_in;                                      \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                               \
+      const int bo_ = base_ + min(16 * t + r, (c).n_out - 1) * (c).s_out;                                          \
+      _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) boff[t][ks] = 4 * min(bo_ + ks * step_, kChainCoreMax - 1); \
+    }                                                                                                              \
+  }
+#define TNML_B_READ(HALF)                                                                                          \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) bv[t][ks] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sC[HALF]) + boff[t][ks]);
+  int soff[NT];                           // this lane's place in an environment slot: [bond o = 16 t + r][samples s0 + 4 q ..]
+#pragma unroll
+  for (int t = 0; t < NT; ++t) soff[t] = (16 * t + r) * b_pad + s0 + 4 * q;
+  ChainSite cs = sites[0], c1 = sites[min(1, n_sites - 1)];
+  TNML_CORE_LOAD(cs);
+  float av[NKS], bv[NT][NKS];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) bv[t][ks] = 0.f;
+  {
+    const float x0 = TNML_X_AT(cs);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) av[ks] = 0.f;
+    if (half == 0) av[0] = x0;            // the chain starts from the scalar 1 (n_in == 1)
+  }
+  TNML_CORE_PUT(sC[0]);
+  TNML_B_OFFSETS(cs);
+  TNML_B_READ(0);
+#ifdef TNML_CHAIN_STAMPS
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  // one site; PAR = i & 1 is the LDS half its core lies in (compile time)
+#define TNML_SITE(PAR)                                                                                             \
+  {                                                                                                                \
+    const bool more = i + 1 < n_sites;                                                                             \
+    TNML_STAMP(0);                                                                                                 \
+    const ChainSite c2 = sites[min(i + 2, n_sites - 1)];          /* wanted one site from now */                   \
+    float xnext = 0.f;                                                                                             \
+    if (more) { TNML_CORE_LOAD(c1); xnext = TNML_X_AT(c1); }       /* travel while this site is computed */        \
+    if ((i & (kChainBlock - 1)) == 0) __hip_atomic_store(&sProg, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    TNML_STAMP(1);                                                                                                 \
+        fvec4 acc[NT], acb[NT];               /* two accumulators per tile: four independent MFMA chains; no branch */ \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) { acc[t] = fvec4{0.f, 0.f, 0.f, 0.f}; acb[t] = fvec4{0.f, 0.f, 0.f, 0.f}; } \
+    _Pragma("unroll") for (int ks = 0; ks < NKS; ks += 2)                                                          \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                             \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[t][ks], acc[t], 0, 0, 0);                         \
+        if (ks + 1 < NKS) acb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks + 1], bv[t][ks + 1], acb[t], 0, 0, 0); \
+      }                                                                                                            \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] += acb[t];                                               \
+    TNML_STAMP(2);                                                                                                 \
+    /* the next core goes to the other half of the LDS area BEFORE this site's environment is stored: the wait */  \
+    /* for its loads (requested a whole site ago) must not also be a wait for stores issued a moment ago */        \
+    if (more) { TNML_CORE_PUT(sC[1 - PAR]); }                                                                      \
+    TNML_STAMP(3);                                                                                                 \
+    /* result: rows = samples 4 q + reg, column o = 16 t + r */                                                    \
+    float *out = cs.env_out_off >= 0 ? (env_base ? env_base + cs.env_out_off : nullptr) : f;                       \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                               \
+      const int o = 16 * t + r;                                                                                    \
+      const bool valid = o < cs.n_out;                                                                             \
+      if (out && valid) *reinterpret_cast<fvec4 *>(out + soff[t]) = acc[t];                                        \
+      /* the next site reads env[s][in = o] as av[ks] of the lanes with half == (o & 1), ks = o >> 1 */            \
+      const int colp = (o & 1) * 16 + (o >> 1);                                                                    \
+      _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) sE[(4 * q + reg) * kChainLD + colp] = valid ? acc[t][reg] : 0.f; \
+    }                                                                                                              \
+    TNML_STAMP(4);                                                                                                 \
+    if (more) {                                                                                                    \
+      const fvec4 *erow = reinterpret_cast<const fvec4 *>(sE + r * kChainLD + half * 16);                          \
+      _Pragma("unroll") for (int k4 = 0; k4 < (NKS + 3) / 4; ++k4) {                                       \
+        const fvec4 v = erow[k4];                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) if (4 * k4 + e < NKS) av[4 * k4 + e] = v[e] * xnext;         \
+      }                                                                                                            \
+      TNML_STAMP(5);                                                                                               \
+      if (c1.s_in != cs.s_in || c1.s_d != cs.s_d || c1.s_out != cs.s_out || c1.n_out != cs.n_out) { TNML_B_OFFSETS(c1); } \
+      TNML_B_READ(1 - PAR);                                                                                        \
+    }                                                                                                              \
+    TNML_STAMP(6);                                                                                                 \
+    cs = c1; c1 = c2;                                                                                              \
+    TNML_STAMP_OUT();                                                                                              \
+  }
+  for (int i = 0; i < n_sites; ++i) {
+    TNML_SITE(0);
+    if (++i >= n_sites) break;
+    TNML_SITE(1);
+  }
+#undef TNML_SITE
+#undef TNML_CORE_LOAD
+#undef TNML_CORE_PUT
+#undef TNML_X_AT
+#undef TNML_B_OFFSETS
+#undef TNML_B_READ
+}
+
 void launch_env_chain(const ChainSite *sites_dev, int n_sites, const float *cores, const float *labcore,
                       const float *X, float *env_base, float *f, int b, int b_pad, int L, int Mmax,
-                      float *logmax_out, hipStream_t st) {
+                      float *logmax_out, hipStream_t st, bool force_plain) {
   const int mo = Mmax > L ? Mmax : L;
   size_t lds = ((size_t)Mmax * kD * mo + 2 * (size_t)mo * kChainTS + kChainTS * kD + 2 * kChainTS) * sizeof(float);
   if (logmax_out)
     hipLaunchKernelGGL(env_chain_kernel<true>, dim3(b_pad / kChainTS), dim3(kChainThreads), lds, st, sites_dev,
                        n_sites, cores, labcore, X, env_base, f, b, b_pad, L, Mmax, logmax_out);
+  else if (!force_plain && mo <= 32 && (Mmax & 1) == 0) {    // (core slots of an even bond capacity are 16-byte aligned: the cores travel as 16-byte loads)
+    const int n4 = (Mmax * kD * mo + 3) / 4;
+    const dim3 grid(b_pad / 16), block(128);
+#define TNML_CHAIN_GO(NV4, NT, NKS) hipLaunchKernelGGL((env_chain_mfma_kernel<NV4, NT, NKS>), grid, block, 0, st, sites_dev, n_sites, cores, labcore, X, env_base, f, b_pad)
+    (void)n4;
+    if (mo <= 10) TNML_CHAIN_GO(1, 1, 5);
+    else if (mo <= 16) TNML_CHAIN_GO(2, 1, 8);
+    else if (mo <= 20) TNML_CHAIN_GO(4, 2, 10);
+    else if (mo <= 24) TNML_CHAIN_GO(5, 2, 12);
+    else TNML_CHAIN_GO(8, 2, 16);
+#undef TNML_CHAIN_GO
+  }
   else
     hipLaunchKernelGGL(env_chain_kernel<false>, dim3(b_pad / kChainTS), dim3(kChainThreads), lds, st, sites_dev,
                        n_sites, cores, labcore, X, env_base, f, b, b_pad, L, Mmax, logmax_out);
@@ -386,7 +586,6 @@ __global__ __launch_bounds__(kWideThreads) void f_only_kernel(WideParams p, int 
 // Lane maps: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
 // C/D col = lane & 15, row = 4 (lane >> 4) + reg.
 // ------------------------------------------------------------------------------------------
-typedef float fvec4 __attribute__((ext_vector_type(4)));
 constexpr int kMfmaThreads = 512;
 constexpr int kTSP = kTS + 1;           // sample stride of the LDS operand arrays (bank spread)
 

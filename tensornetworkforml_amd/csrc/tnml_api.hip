@@ -102,6 +102,7 @@ struct tnml_ctx {
   BigScratch big{};                          // HBM scratch of the large-tensor path, allocated on first use
   bool big_ready = false;
   bool force_big = false;                    // tnml_set_narrow_path
+  bool chain_plain = false;                  // tnml_set_chain_path
   float *prepB = nullptr;                    // fused narrow launch: merged tensor / L2 term from the helper workgroups
   double *prepG = nullptr;
   unsigned *sync = nullptr;
@@ -602,7 +603,7 @@ static int run_chain(tnml_ctx *c, bool logmode) {
   if (c->profile) HIP_TRY(hipEventRecord(c->pev0, c->stream));
   launch_env_chain((const ChainSite *)c->tables, N, c->cores, c->lab[c->lab_cur], c->X,
                    right_envs ? c->Renv : c->Lenv, c->f, c->b, c->b_pad, L, c->Mmax,
-                   logmode ? c->slabs : nullptr, c->stream);
+                   logmode ? c->slabs : nullptr, c->stream, c->chain_plain);
   HIP_TRY(hipGetLastError());
   if (c->profile) {
     HIP_TRY(hipEventRecord(c->pev1, c->stream));
@@ -660,7 +661,7 @@ extern "C" int tnml_predict(tnml_ctx *c, const float *X, int b, float *f_out) {
   int rc = upload_chain_table(c);
   if (rc) return rc;
   launch_env_chain((const ChainSite *)c->tables, N, c->cores, c->lab[c->lab_cur], c->Xpred, nullptr, c->fpred, b, bpad, L,
-                   c->Mmax, nullptr, c->stream);
+                   c->Mmax, nullptr, c->stream, c->chain_plain);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy2DAsync(f_out, (size_t)b * sizeof(float), c->fpred, (size_t)bpad * sizeof(float), (size_t)b * sizeof(float),
                            L, hipMemcpyDeviceToHost, c->stream));
@@ -1582,6 +1583,12 @@ extern "C" int tnml_set_trunc_threshold(tnml_ctx *c, double threshold) {
 extern "C" int tnml_set_narrow_path(tnml_ctx *c, int force_large) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   c->force_big = force_large != 0;
+  return TNML_OK;
+}
+
+extern "C" int tnml_set_chain_path(tnml_ctx *c, int force_plain) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  c->chain_plain = force_plain != 0;
   return TNML_OK;
 }
 

@@ -152,7 +152,7 @@ struct NormChainSite {
 void launch_transpose_input(const float *X_bnd, float *X_nbd, int b, int b_pad, int N, hipStream_t st);
 void launch_env_chain(const ChainSite *sites_dev, int n_sites, const float *cores, const float *labcore,
                       const float *X, float *env_base, float *f, int b, int b_pad, int L, int Mmax,
-                      float *logmax_out, hipStream_t st);
+                      float *logmax_out, hipStream_t st, bool force_plain = false);
 constexpr int kChainSamplesPerBlock = 16;
 // slice-wise pre-computation of the merged tensor and its L2 term (small_gemm_device.h: prep_slice_block)
 struct PrepParams {

@@ -445,7 +445,18 @@ def test_persistent_sweep_matches_per_step_launches_and_oracle(policy, M, N, b, 
         ctx.profile_reset()
         ctxs.append(ctx)
     X64 = X.astype(np.float64)
+    worst = {}
     for sw in range(2):
+        if sw == 1:
+            # Sweep 2 starts from ONE state everywhere (the persistent context's cores after sweep 1, float32 -> float64 for
+            # the oracle): these untrained chains amplify float32 rounding -- free-running second sweeps of the three device
+            # forms differed from the oracle by 2e-3 .. 8e-3 depending on nothing but the association order of the forward
+            # chain -- so each sweep is compared on its own.
+            cores_d, bond_d, lp = ctxs[0].get_cores()
+            st = mo.MPSState(N, D, L, M, [c.astype(np.float64) for c in cores_d], l_pos=int(lp))
+            assert list(st.bond) == [int(v) for v in bond_d]
+            for ctx in ctxs[1:]:
+                ctx.set_cores(cores_d, int(lp))
         f_o = mo.forward(st, X64)
         left_dir = st.l_pos == N - 1
         vh = [[], []]
@@ -456,17 +467,22 @@ def test_persistent_sweep_matches_per_step_launches_and_oracle(policy, M, N, b, 
             ctx.forward()
             met, f_d = ctx.sweep(left_dir, N - 1, True, kw['lr'], kw['weight_dec'], True, kw['act_fn'], kw['loss_fn'], kw['T'], policy)
             res.append((met, f_d))
-            assert relerr(f_d, f_o) < 5e-3, sw
-            assert np.abs(met[:, 0] - np.array(vh[0])).max() <= 2.0 / b + 1e-6
-            assert np.abs(met[:, 1] - np.array(vh[1])).max() < 2e-3
+            worst['f_vs_oracle'] = max(worst.get('f_vs_oracle', 0), relerr(f_d, f_o))
+            worst['acc'] = max(worst.get('acc', 0), np.abs(met[:, 0] - np.array(vh[0])).max() * b)
+            worst['mae'] = max(worst.get('mae', 0), np.abs(met[:, 1] - np.array(vh[1])).max())
             _, bond_d, lp = ctx.get_cores()
             assert list(bond_d) == list(st.bond) and lp == st.l_pos
         # the two device paths: the same sums in another association order
-        assert relerr(res[0][1], res[1][1]) < (2e-5 if sw == 0 else 5e-3), sw      # observed 1e-6 / 2e-3 (both amplify the oracle's 2.6e-3)
+        worst['f_paths'] = max(worst.get('f_paths', 0), relerr(res[0][1], res[1][1]))
         assert np.abs(res[0][0][:, 0] - res[1][0][:, 0]).max() <= 1.0 / b + 1e-6
         assert np.abs(res[0][0][:, 1] - res[1][0][:, 1]).max() < 2e-4
         np.testing.assert_array_equal(res[0][1], res[2][1])       # the same arithmetic in one kernel or three
         np.testing.assert_array_equal(res[0][0], res[2][0])
+    print('persistent sweep', policy, M, N, b, L, {k: '%.2e' % v for k, v in worst.items()})
+    assert worst['f_vs_oracle'] < 2e-3      # observed <= 2.6e-4 (a whole sweep of an untrained chain, from a common start)
+    assert worst['acc'] <= 2.0 + 1e-3       # samples
+    assert worst['mae'] < 2e-3
+    assert worst['f_paths'] < 5e-4          # observed <= 6e-5
     # the persistent context made one launch per sweep, the other one N - 1 (+ the launch that starts a sweep)
     assert ctxs[0].counters()['launches'] == 2 and ctxs[0].counters()['sweep_steps'] == 2 * (N - 1) and ctxs[2].counters()['launches'] == 2
     assert ctxs[1].counters()['launches'] >= 2 * (N - 1)

@@ -98,12 +98,15 @@ def test_large_bond_goldens(name, large):
             assert list(bond_d) == [int(v) for v in d[pre + 'bond']]
             k += 1
     print(name, 'large' if large else 'lds', {kk: '%.2e' % v for kk, v in worst.items()})
-    assert worst['f'] < 5e-3          # observed <= 2e-5
-    assert worst['sigma'] < 2e-3      # observed <= 1e-6
+    # observed over the four cases (round 3): f 6e-7 .. 2.9e-6, sigma 1.2e-5 .. 5.1e-5 of sigma_max, MAE <= 3.7e-7, L2 loss <= 3e-6
+    assert worst['f'] < 3e-5
+    assert worst['sigma'] < 5e-4
     assert worst['acc'] < 1e-6
-    assert worst['mae'] < 2e-3
-    assert worst['l2'] < 1e-3
-    assert relerr(ctx.forward(), d['final_f']) < 5e-3
+    assert worst['mae'] < 4e-6
+    assert worst['l2'] < 3e-5
+    final = relerr(ctx.forward(), d['final_f'])
+    print(name, 'final f', '%.2e' % final)
+    assert final < 2e-4
     ctx.close()
 
 
@@ -186,12 +189,15 @@ def test_bench_config_true_shape(cfg, N, M, b, L):
     obs['fresh'] = relerr(ctx.forward(), mo.forward(st, X2.astype(np.float64)))
     ctx.close()
     print(cfg, 'true shape', {k: '%.2e' % v for k, v in obs.items()}, '%.0f s' % (time.time() - t0))
-    assert obs['fwd0'] < 1e-4 and obs['fwd1'] < 1e-4        # observed 8e-8 / 1e-5
-    assert obs['f0'] < 2e-3                                  # observed 1e-5 over 783 free-running steps
-    assert obs['acc0'] <= 1.0 / b + 1e-6 and obs['mae0'] < 1e-4
-    assert obs['f1_median_chunk'] < 5e-4 and obs['f1_worst_chunk'] < 3e-2
-    assert obs['acc1'] <= 3.0 / b + 1e-6 and obs['mae1'] < 2e-3
-    assert obs['fresh'] < 2e-3                               # same cores on both sides; observed 4e-4 (float32 chain of 784 sites)
+    # observed (round 3, c2 / c3): fwd0 4e-7 / 5e-7, fwd1 1.5e-6 / 2.9e-6, f0 1.5e-4 / 4.2e-4 (783 free-running steps), f1 median
+    # 1.3e-6 / 7.9e-5, worst chunk 4.2e-3 / 2.7e-3 (a tail statistic of an amplifying dynamics, see `resync`), accuracy 0 / 1
+    # sample, MAE 1e-7, fresh input 1.6e-4 / 7.7e-5
+    assert obs['fwd0'] < 5e-6 and obs['fwd1'] < 3e-5
+    assert obs['f0'] < 2e-3
+    assert obs['acc0'] <= 1.0 / b + 1e-6 and obs['mae0'] < 1e-6
+    assert obs['f1_median_chunk'] < 5e-4 and obs['f1_worst_chunk'] < 2e-2
+    assert obs['acc1'] <= 2.0 / b + 1e-6 and obs['mae1'] < 1e-6
+    assert obs['fresh'] < 1e-3                               # same cores on both sides (float32 chain of 784 sites)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -247,15 +253,111 @@ def test_c5_true_matrix_shape():
     ctx.debug_enable(False)
     print('c5 matrix shape', {k: '%.2e' % v for k, v in worst.items()}, sorted(shapes)[-3:])
     assert (100, 1000) in shapes and (1000, 100) in shapes      # the C5 merged tensor, both directions
-    assert worst['f'] < 5e-3
+    # observed (round 3): f 3.2e-4, sigma 3.9e-4 of sigma_max (46 free-running steps), accuracy 1 sample, MAE 1e-7
+    assert worst['f'] < 2e-3
     assert worst['sigma'] < 2e-3
     assert worst['prod'] < 3e-4      # observed 4e-5 .. 1e-4: best rank-m approximation of a tensor whose singular values crowd at the cut
-    assert worst['acc'] <= 3.0 / b + 1e-6
-    assert worst['mae'] < 2e-3
+    assert worst['acc'] <= 2.0 / b + 1e-6
+    assert worst['mae'] < 2e-6
     X2, _ = synth(N, b, L, 78, zero_frac=0.6)
     ctx.set_input(X2, y)
-    assert relerr(ctx.forward(), mo.forward(st, X2.astype(np.float64))) < 5e-3
+    fresh = relerr(ctx.forward(), mo.forward(st, X2.astype(np.float64)))
+    print('c5 matrix shape, fresh input', '%.2e' % fresh)
+    assert fresh < 5e-3
     ctx.close()
+
+
+def test_c5_full_length_properties():
+    """C5 at its FULL length (N = 784, bond 50, ten labels, batch 5000): one right sweep, the device alone (an oracle step
+    costs a second here).  Checked through quantities that need no second trajectory: at every 40th step the singular values
+    and the product of the two new cores against LAPACK on the device's OWN updated tensor, the bond the step leaves, finite
+    f and metrics; at the end `forward` on the device's cores against one float64 oracle forward on the same cores."""
+    N, M, b, L, D = 784, 50, 5000, 10, 2
+    X, y = synth(N, b, L, 55)
+    rng = np.random.default_rng(8)
+    cores32 = [c.astype(np.float32) for c in mo.random_cores(N, M, D, L, rng=rng, scale=M * 0.5 * 0.64 * D)]
+    ctx = hip().Context(N, D, L, M, b)
+    ctx.set_cores(cores32, 0)
+    ctx.set_input(X, y)
+    ctx.scale_cores(1.0 / float(np.exp(ctx.forward_logabsmax() / N)))     # calibration as Network.__init__ does it
+    f0 = ctx.forward()
+    assert np.isfinite(f0).all() and 0.1 < np.abs(f0).max() < 10.0
+    hp = (1e-3, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
+    worst = dict(sigma=0.0, prod=0.0)
+    checked = 0
+    for j in range(N - 1):
+        check = j % 40 == 20 or j in (0, 5, N - 2)
+        ctx.debug_enable(check)
+        met, f_d = ctx.sweep(False, 1, j == 0, *hp)
+        assert np.isfinite(f_d).all() and np.isfinite(met).all(), j
+        if not check:
+            continue
+        cores_d, bond_d, lp = ctx.get_cores()
+        assert lp == j + 1
+        ml, mr = (1 if j == 0 else int(bond_d[j - 1])), (1 if j + 1 == N - 1 else int(bond_d[j + 1]))
+        m = int(bond_d[j])
+        assert m == hip().trunc_rank('fixed', False, j, N, ml, D, mr, L, M) == min(M, D * ml, D * mr * L)
+        Bm = ctx.step_debug('B_new').reshape(ml * D, D * mr * L)
+        U, S, Vh = np.linalg.svd(Bm, full_matrices=False)
+        sig = ctx.step_debug('sigma')
+        worst['sigma'] = max(worst['sigma'], float(np.abs(sig[:len(S)] - S).max() / S.max()))
+        A, C = cores_d[j].astype(np.float64), cores_d[j + 1].astype(np.float64)
+        prod = np.einsum('adk,kecl->adecl', A, C).reshape(ml * D, D * mr * L)
+        best = (U[:, :m] * S[:m]) @ Vh[:m]
+        worst['prod'] = max(worst['prod'], float(np.abs(prod - best).max() / np.abs(Bm).max()))
+        checked += 1
+    ctx.debug_enable(False)
+    cores_d, bond_d, lp = ctx.get_cores()
+    assert lp == N - 1 and max(bond_d) == M and int(np.sum(np.asarray(bond_d) == M)) >= N - 1 - 12
+    st = mo.MPSState(N, D, L, M, [c.astype(np.float64) for c in cores_d], l_pos=N - 1)
+    Xs = X[:500]                                    # the oracle's forward on 500 of the samples (3 s instead of 29)
+    f_o = mo.forward(st, Xs.astype(np.float64))
+    f_d = ctx.forward()[:, :500]
+    fwd = relerr(f_d, f_o)
+    ctx.close()
+    print('c5 full length: %d steps checked' % checked, {k: '%.2e' % v for k, v in worst.items()}, 'forward %.2e' % fwd)
+    assert checked >= 20
+    assert worst['sigma'] < 1e-5     # observed 1.2e-6 of sigma_max
+    assert worst['prod'] < 1.5e-4    # observed 1.7e-5 of max|B|
+    assert fwd < 7e-5                # observed 7e-6
+
+
+def test_c3_reference_policy_true_shape():
+    """C3's shape under the REFERENCE truncation rule (m = left bond: every bond collapses to 2 during the first sweep, so the
+    steps are short and take the one-level reduction over all 157 partial pre-gradients -- bench.py --policy reference): three
+    sweeps free-running against `mo.sweep` at N = 784, b = 5000."""
+    N, M, b, L, D = 784, 20, 5000, 2, 2
+    X, y = synth(N, b, L, 4242)
+    X64 = X.astype(np.float64)
+    st, cores32 = calibrated_pair(N, M, D, L, X, 17)
+    ctx = hip().Context(N, D, L, M, b)
+    ctx.set_cores(cores32, 0)
+    ctx.set_input(X, y)
+    hp = (HP['lr'], HP['weight_dec'], True, HP['act_fn'], HP['loss_fn'], HP['T'], 'reference')
+    okw = dict(L2_flag=True, act_fn=HP['act_fn'], loss_fn=HP['loss_fn'], T=HP['T'], trunc='reference')
+    obs = {}
+    for sw in range(3):
+        f_o = mo.forward(st, X64)
+        obs['fwd%d' % sw] = relerr(ctx.forward(), f_o)
+        left = st.l_pos == N - 1
+        vh = [[], []]
+        f_o = mo.sweep(st, X64, y, f_o, HP['lr'], HP['weight_dec'], left_dir=left, var_hist=vh, **okw)
+        met, f_d = ctx.sweep(left, N - 1, True, *hp)
+        obs['f%d' % sw] = relerr(f_d, f_o)
+        obs['acc%d' % sw] = float(np.abs(met[:, 0] - np.array(vh[0])).max()) * b
+        obs['mae%d' % sw] = float(np.abs(met[:, 1] - np.array(vh[1])).max())
+        _, bond_d, lp = ctx.get_cores()
+        assert list(bond_d) == list(st.bond) and lp == st.l_pos
+    assert max(st.bond) <= 4                       # the reference rule has collapsed the chain
+    ctx.close()
+    print('c3 reference policy', {k: '%.2e' % v for k, v in obs.items()})
+    # observed (free-running, so the forward of sweep k carries the difference sweep k - 1 left): forward 3e-7, 1.9e-6, 6.8e-4;
+    # f after the sweep 1.9e-6, 6.8e-4, 2.3e-4; accuracy of single steps 1, 1, 2 samples of 5000; MAE 1.3e-7
+    for sw in range(3):
+        assert obs['fwd%d' % sw] < (5e-6 if sw == 0 else 5e-3)
+        assert obs['f%d' % sw] < (2e-5 if sw == 0 else 5e-3)
+        assert obs['acc%d' % sw] <= 4.0 + 1e-3     # samples of 5000
+        assert obs['mae%d' % sw] < 2e-6
 
 
 def test_largest_matrix_side_of_the_large_path():
@@ -380,10 +482,15 @@ def test_accuracy_parity_n196_reference_policy():
 def test_accuracy_parity_n196_fixed_bond20():
     """N = 196, bond 20 under the fixed policy, four sweeps over four batches.  Under this policy the training dynamics is
     unstable by itself (the float64 oracle's accuracy on this task goes 0.84, 0.84, 0.54, 0.57 over the four sweeps), so
-    the device runs free and the oracle is re-based on the device's cores every 15 steps (see `resync`): training accuracy
-    of every step and held-out accuracy after every sweep, device vs oracle, within 0.5 %."""
+    the device runs free and the oracle is re-based on the device's cores every 5 steps (see `resync`): training accuracy
+    of every step within 0.2 % and held-out accuracy after every sweep within 0.5 %, device vs oracle.  How fast this
+    dynamics amplifies a float32-sized perturbation is measured, oracle against oracle, by
+    tests/test_oracle_golden.py::test_float32_rounding_is_amplified_by_the_sweep_dynamics; on the device the same comparison
+    in chunks of 15 steps gave 0.3 % with the plain-FMA forward chain and 1.6 % (2 of 780 steps above 0.5 %) with the
+    matrix-core chain, whose environments are as close to the float64 ones (7e-7 against 5e-7:
+    tests/emulation/chain_precision_probe.py)."""
     N, M, b, L, D = 196, 20, 1000, 2, 2
-    chunk = 15
+    chunk = 5
     assert (N - 1) % chunk == 0
     X, y = _diag14(5)
     Xh, yh = X[4000:], y[4000:]
@@ -419,5 +526,5 @@ def test_accuracy_parity_n196_fixed_bond20():
         held.append((acc_d, acc_o))
     ctx.close()
     print('N=196 fixed bond 20: worst per-step training accuracy gap %.4f; held-out (device, oracle) per sweep:' % worst_step, held)
-    assert worst_step <= 0.005 + 1e-6      # one sample of the 200-sample batch is exactly 0.5 % (float32 metric)
+    assert worst_step <= 0.002 + 1e-6      # observed 0.001: one sample of the 1000-sample batch
     assert max(abs(a - o) for a, o in held) <= 0.005
