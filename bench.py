@@ -254,11 +254,16 @@ def main():
                     sweeps_per_svd=sw_tot / max(n_svd, 1), rounds_per_svd=rounds_tot / max(n_svd, 1),
                     cholesky_fraction=chol / max(n_svd, 1))
 
+    # phase markers (tnml_marker: an empty kernel of `id` workgroups) cut a rocprofv3 trace of this command to one phase
+    # (tools/rocprof_summary.py): 1 warm-up | 2 timed passes | 3 break-down + per-kernel passes | 4 resident | 5 | 6 cold | 7
     ctx.profile_reset()
     ctx.profile_enable(2)
+    ctx.marker(1)
     for _ in range(args.warmup):
         one_pass()
+    ctx.marker(2)
     main_run = timed(args.steps)
+    ctx.marker(3)
     dt = main_run['dt']
 
     # SURVEY.md 8.4 break-down: the environment build (forward) and the host -> device hand-over of one batch on their own
@@ -351,14 +356,20 @@ def main():
                            'launches_timed': main_run['launches'] if persistent else step_launches, 'steps_timed': step_launches,
                            'note': 'one launch = one whole sweep (persistent kernel) or one whole sweep step; the step is bound by the sequential SVD of its merged tensor '
                                    '(critical_path below), not by HBM'}
-        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_%s.json' % args.config)
+        # HBM traffic from the committed counter passes (separate rocprofv3 --pmc runs of this command, cut to the timed passes by
+        # the phase markers; never collected inside a bench run).  gfx950: FETCH_SIZE counts half of a coalesced read stream
+        # (MI355X_MICROARCH.md, HBM section): x 2.
+        pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_%s.json' % args.config)
         if os.path.exists(pmc) and args.policy == 'fixed' and not args.no_l2 and not args.classic:
-            w = json.load(open(pmc)).get('step_pipe_kernel', {})
+            allk = json.load(open(pmc))
+            scope = 'timed' if 'timed' in allk else 'whole_process'
+            kname = 'sweep_persist_kernel' if persistent else 'step_pipe_kernel'
+            w = allk.get(scope, {}).get(kname, {})
             if 'FETCH_SIZE' in w and 'WRITE_SIZE' in w:
-                # gfx950: FETCH_SIZE counts half of a coalesced read stream (MI355X_MICROARCH.md, HBM section)
+                per_launch = (2.0 * w['FETCH_SIZE']['mean_KB'] + w['WRITE_SIZE']['mean_KB']) * 1024.0
                 out['roofline']['traffic_from_profiles'] = {
-                    'bytes_per_launch': (2.0 * w['FETCH_SIZE']['mean_KB'] + w['WRITE_SIZE']['mean_KB']) * 1024.0,
-                    'source': 'profiles/r02_pmc_%s.json (separate rocprofv3 --pmc passes, not this run)' % args.config}
+                    'bytes_per_launch': per_launch, 'bytes_per_step': per_launch / ((N - 1) if persistent else 1),
+                    'source': 'profiles/r03_pmc_%s.json [%s][%s] (separate rocprofv3 --pmc passes, not this run)' % (args.config, scope, kname)}
 
     if rank == 0 and not args.no_kernel_profile:
         # per-kernel device time with HIP events around every launch (two more passes; synchronises after each launch)
@@ -413,7 +424,9 @@ def main():
         ctx.select_batch(0)
         for _ in range(max(args.warmup, 2)):
             one_pass(rotate=False)
+        ctx.marker(4)
         r = timed(args.steps, rotate=False)
+        ctx.marker(5)
         out['resident_batch'] = {'value': (1 if strong else world) * sweep_steps / r['dt'], 'unit': 'sweep-steps/s',
                                  'jacobi_sweeps_per_svd': r['sweeps_per_svd'], 'cholesky_fraction': r['cholesky_fraction']}
 
@@ -422,7 +435,9 @@ def main():
         # training batches, where the merged tensors are far from their SVD form
         ctx.select_batch(0)
         init_network()
+        ctx.marker(6)
         r = timed(2)
+        ctx.marker(7)
         out['cold_start'] = {'value': (1 if strong else world) * 2 * (N - 1) / r['dt'], 'unit': 'sweep-steps/s', 'passes': 2,
                              'jacobi_sweeps_per_svd': r['sweeps_per_svd'], 'cholesky_fraction': r['cholesky_fraction']}
 

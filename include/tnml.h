@@ -184,7 +184,9 @@ int tnml_set_persistent(tnml_ctx *ctx, int on);
 
 /* tnml_sweep enqueues every launch of its n_steps steps without waiting (2 - 14 launches per step).  A profiler that
  * intercepts dispatches (rocprofv3 --pmc serialises them and keeps per-dispatch state) can be overrun by tens of
- * thousands of queued launches; n_steps > 0 drains the stream every n_steps steps, 0 (default) never. */
+ * thousands of queued launches; n_steps > 0 drains the stream every n_steps steps, 0 never.  Default 256: at most ~3600
+ * dispatches outstanding on the large-tensor path, one host round trip per 14 ms of a C3 sweep (the persistent sweep is one
+ * launch and never drains). */
 int tnml_set_sync_interval(tnml_ctx *ctx, int n_steps);
 
 /* The batch-independent part of a step (update_B's tail, compute_L2_reg, tensor_svd) runs in one
@@ -227,6 +229,10 @@ int tnml_batch(tnml_ctx *ctx);
 /* ---- measurement ------------------------------------------------------------------------ */
 /* HIP-event timing on the context's own stream (torch.cuda.Event would not see it) */
 int tnml_timer_start(tnml_ctx *ctx);
+/* phase boundary visible to a profiler: an empty kernel `tnml_phase_marker_kernel` of `id` workgroups of 64 threads (1 <= id <=
+ * 1024) on the context's stream; bench.py brackets its warm-up / timed / resident / cold passes with it and
+ * tools/rocprof_summary.py cuts kernel traces and counter passes to the window between two markers */
+int tnml_marker(tnml_ctx *ctx, int id);
 int tnml_timer_stop(tnml_ctx *ctx, double *elapsed_ms);
 /* tnml_profile_enable(ctx, 1): accumulated per-kernel device time (ms) and launch counts since the last reset, measured
  * with HIP events around each launch (synchronises after every launch: slows the sweep; break-downs only)

@@ -28,7 +28,7 @@ SYMBOLS = [
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
     'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict', 'tnml_set_trunc_threshold',
     'tnml_set_sync_interval', 'tnml_set_step_pipeline', 'tnml_stage_batch', 'tnml_select_batch', 'tnml_get_counters',
-    'tnml_svd_stats_ex', 'tnml_set_persistent', 'tnml_set_chain_path',
+    'tnml_svd_stats_ex', 'tnml_set_persistent', 'tnml_set_chain_path', 'tnml_marker',
 ]
 
 
@@ -93,6 +93,7 @@ def lib():
         L.tnml_set_svd_stop.argtypes = [vp, C.c_double]
         L.tnml_set_narrow_path.argtypes = [vp, C.c_int]
         L.tnml_set_chain_path.argtypes = [vp, C.c_int]
+        L.tnml_marker.argtypes = [vp, C.c_int]
         L.tnml_predict.argtypes = [vp, f32p, C.c_int, f32p]
         L.tnml_set_trunc_threshold.argtypes = [vp, C.c_double]
         L.tnml_set_sync_interval.argtypes = [vp, C.c_int]
@@ -371,6 +372,10 @@ class Context:
         _chk(lib().tnml_synchronize(self._h))
 
     # ---- measurement
+    def marker(self, marker_id):
+        """Phase boundary for profilers: an empty kernel of `marker_id` workgroups on the context's stream."""
+        _chk(lib().tnml_marker(self._h, int(marker_id)))
+
     def timer_start(self):
         _chk(lib().tnml_timer_start(self._h))
 

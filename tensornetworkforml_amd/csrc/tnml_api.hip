@@ -68,7 +68,7 @@ struct tnml_ctx {
   int last_bsize = 0, last_n = 0, last_h = 0, last_g = 0, last_left_dir = 0;
   bool debug = false, profile = false, stamps = false;
   bool check_launches = false;               // tnml_debug_enable bit 2: read the launch status back after every kernel launch
-  int sync_interval = 0;                     // tnml_set_sync_interval: drain the stream every so many steps (0 = never)
+  int sync_interval = 256;                   // tnml_set_sync_interval: drain the stream every so many steps (0 = never)
   double svd_stop2 = kSvdStop2Default;
   double chol_thr = kCholThrDefault;         // off(G) / trace(G) above which the pivoted-Cholesky step runs (0 disables it)
   double trunc_thr = 0.999;                  // adaptive truncation threshold (tensor_svd's default argument)
@@ -1677,6 +1677,17 @@ extern "C" int tnml_get_step_debug(tnml_ctx *c, int what, double *out, size_t ca
 // ---------------------------------------------------------------------------------------------
 // measurement
 // ---------------------------------------------------------------------------------------------
+// A phase boundary a profiler can see: an empty kernel of `id` workgroups on the context's stream.  In a rocprofv3 kernel trace (and
+// in a --pmc pass, which lists dispatches in the same order) it appears as `tnml_phase_marker_kernel` with Grid_Size = 64 * id, so a
+// trace can be cut to the launches between two markers (tools/rocprof_summary.py) -- no clock domain to reconcile, no marker API.
+__global__ void tnml_phase_marker_kernel() {}
+extern "C" int tnml_marker(tnml_ctx *c, int id) {
+  if (!c || id < 1 || id > 1024) return fail(TNML_ERR_ARG, "marker id outside [1, 1024]");
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(tnml_phase_marker_kernel, dim3(id), dim3(64), 0, c->stream);
+  HIP_TRY(hipGetLastError());
+  return TNML_OK;
+}
 extern "C" int tnml_timer_start(tnml_ctx *c) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
