@@ -553,8 +553,9 @@ size_t big_jacobi_lds_bytes(int n) {
 static thread_local char g_big_err[256];
 const char *big_launch_error() { return g_big_err; }
 
-template <class K, class... Args>
-static bool big_launch(const char *name, bool check, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+// (two halves around a launch that names its kernel directly: a launch through a function-pointer parameter is dropped by clang
+// when the host side is built with -fsanitize=undefined, see san/hip_stub.cpp)
+static bool big_launch_ok(const char *name, dim3 grid, dim3 block, size_t lds) {
   const unsigned long long nthreads = (unsigned long long)block.x * block.y * block.z;
   if (grid.x < 1 || grid.y < 1 || grid.z < 1 || grid.x > 0x7fffffffu || grid.y > 65535u || grid.z > 65535u ||
       nthreads < 1 || nthreads > 1024 || lds > 160 * 1024) {
@@ -562,7 +563,9 @@ static bool big_launch(const char *name, bool check, K kernel, dim3 grid, dim3 b
              grid.y, grid.z, block.x, block.y, block.z, lds);
     return false;
   }
-  hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  return true;
+}
+static bool big_launch_done(const char *name, bool check, dim3 grid, dim3 block, size_t lds) {
   if (check) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -590,8 +593,14 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   const int nbe = std::min((Bs + kBT - 1) / kBT, 2048);          // one element per thread
   const int nb = std::min((Bs + kBT - 1) / kBT, kBigParts);      // kernels that leave block partials
   const float *Bf = p.Bdirect;
-#define BIG(kern, grid, block, lds, ...) \
-  if (!big_launch(#kern, check, kern, grid, block, lds, st, __VA_ARGS__)) return false
+#define BIG(kern, grid, block, lds, ...)                                          \
+  do {                                                                            \
+    const dim3 g_ = (grid), b_ = (block);                                         \
+    const size_t l_ = (lds);                                                      \
+    if (!big_launch_ok(#kern, g_, b_, l_)) return false;                          \
+    hipLaunchKernelGGL(kern, g_, b_, l_, st, __VA_ARGS__);                        \
+    if (!big_launch_done(#kern, check, g_, b_, l_)) return false;                 \
+  } while (0)
   if (!Bf) {
     if (!skip_prep) BIG(big_merge_kernel, dim3(nbe), dim3(kBT), 0, p, s.Bf);
     Bf = s.Bf;

@@ -107,7 +107,8 @@ __host__ __device__ inline NarrowCarve narrow_carve(unsigned char *base, int h, 
 }
 
 size_t narrow_lds_bytes(int h, int g, int s, int L, int m) {
-  return narrow_carve(nullptr, h, g, s, L, m).bytes + 16;
+  alignas(16) static unsigned char origin[16];          // only distances from it are used (arithmetic on a null pointer is undefined)
+  return narrow_carve(origin, h, g, s, L, m).bytes + 16;
 }
 
 // ------------------------------------------------------------------------------------------

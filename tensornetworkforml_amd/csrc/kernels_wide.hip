@@ -1120,7 +1120,8 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(Wide
 bool launch_wide(const WideParams &p, int nblk, const PrepParams *prep, hipStream_t st, bool *prep_done) {
   *prep_done = false;
   WideMfmaDims dm = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
-  size_t lds = wide_mfma_carve(nullptr, dm, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
+  alignas(16) static float origin[4];                 // only distances from it are used (arithmetic on a null pointer is undefined)
+  size_t lds = wide_mfma_carve(origin, dm, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
   if (lds <= 160 * 1024) {
     PrepParams q{};
     int extra = 0;
@@ -1134,7 +1135,7 @@ bool launch_wide(const WideParams &p, int nblk, const PrepParams *prep, hipStrea
   }
   // operands of a tile exceed LDS: stream the merged tensor through it in chunks
   WideMfmaDims dt = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
-  const size_t ldst = wide_tiled_carve(nullptr, dt, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
+  const size_t ldst = wide_tiled_carve(origin, dt, p.L, p.h, p.hp, p.gp, p.g).floats * sizeof(float);
   if (ldst <= 160 * 1024 && p.L * (kTS / 16) <= 4 * (kMfmaThreads / 64)) {
     hipLaunchKernelGGL(wide_step_mfma_tiled_kernel, dim3(nblk), dim3(kMfmaThreads), ldst, st, p);
     return true;

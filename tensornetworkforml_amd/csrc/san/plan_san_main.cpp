@@ -1,0 +1,115 @@
+// Whole sweeps of the BASELINE shapes planned by the real host code of the library (tnml_api.hip + the launch wrappers, built
+// --cuda-host-only with AddressSanitizer and UBSan) against the stand-in runtime of hip_stub.cpp, which checks every copy and every
+// launch argument block against the allocation registry.  `make san` builds and runs it; tests/test_host_api.py runs `make san`.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <cmath>
+#include "../../../include/tnml.h"
+
+extern "C" void san_stub_report(void);
+extern "C" long san_stub_launches(const char *substr);
+
+#define OK(call)                                                                              \
+  do {                                                                                        \
+    int rc_ = (call);                                                                         \
+    if (rc_ != TNML_OK) { fprintf(stderr, "%s:%d %s -> %d: %s\n", __FILE__, __LINE__, #call, rc_, tnml_last_error()); exit(1); } \
+  } while (0)
+
+struct Cfg { const char *name; int N, M, b, L; int policy; int sweeps; };
+
+static std::vector<int> start_bonds(int N, int M, int D, int L) {
+  std::vector<int> bond(N - 1);
+  for (int i = 0; i < N - 1; ++i) {                       // the reference's initial shapes: full bond M everywhere
+    bond[i] = M;
+  }
+  (void)D; (void)L;
+  return bond;
+}
+
+static void run(const Cfg &c, int mode) {
+  const int D = 2;
+  tnml_ctx *ctx = nullptr;
+  OK(tnml_create(&ctx, c.N, D, c.L, c.M, c.b, 0));
+  // cores: label on site 0, shapes (ml, D, mr[, L]) with the uniform initial bond
+  std::vector<int> bond = start_bonds(c.N, c.M, D, c.L);
+  size_t total = 0;
+  std::vector<size_t> off(c.N + 1, 0);
+  for (int i = 0; i < c.N; ++i) {
+    const int ml = i == 0 ? 1 : bond[i - 1], mr = i == c.N - 1 ? 1 : bond[i];
+    off[i] = total;
+    total += (size_t)ml * D * mr * (i == 0 ? c.L : 1);
+  }
+  off[c.N] = total;
+  std::vector<float> cores(total);
+  for (size_t e = 0; e < total; ++e) cores[e] = 0.1f + 1e-3f * (float)(e % 97);
+  OK(tnml_set_cores(ctx, cores.data(), total, bond.data(), 0));
+  std::vector<float> X((size_t)c.b * c.N * D, 0.5f);
+  std::vector<int> y(c.b);
+  for (int s = 0; s < c.b; ++s) y[s] = s % c.L;
+  OK(tnml_set_input(ctx, X.data(), y.data(), c.b));
+  switch (mode) {
+    case 0: break;                                          // default: persistent sweep
+    case 1: OK(tnml_set_persistent(ctx, 0)); break;         // one launch per step
+    case 2: OK(tnml_set_step_pipeline(ctx, 0)); break;      // classic launch sequence
+    case 3: OK(tnml_set_narrow_path(ctx, 1)); OK(tnml_set_persistent(ctx, 0)); break;   // large-tensor path everywhere
+    case 4: OK(tnml_set_persistent(ctx, 2)); break;         // persistent, one kernel per role
+  }
+  std::vector<float> f((size_t)c.L * c.b), met((size_t)2 * (c.N - 1));
+  double lm = 0;
+  OK(tnml_forward_logabsmax(ctx, &lm));
+  for (int sw = 0; sw < c.sweeps; ++sw) {
+    OK(tnml_forward(ctx, f.data()));
+    const int left = tnml_l_pos(ctx) == c.N - 1;
+    // a sweep in two calls (the second continues mid-chain), as Network.sweep may be driven
+    // (odd sweeps: one call, which the persistent path takes whole)
+    const int n1 = (sw & 1) ? c.N - 1 : ((c.N - 1) / 3 > 0 ? (c.N - 1) / 3 : 1), n2 = c.N - 1 - n1;
+    OK(tnml_sweep(ctx, left, n1, 1, 1e-3f, 1e-3f, 1, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 0.1f, c.policy, met.data(), n2 ? nullptr : f.data()));
+    if (n2) OK(tnml_sweep(ctx, left, n2, 0, 1e-3f, 1e-3f, 1, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 0.1f, c.policy, met.data() + 2 * n1, f.data()));
+    if (tnml_l_pos(ctx) != (left ? 0 : c.N - 1)) { fprintf(stderr, "%s: label at %d after a %s sweep\n", c.name, tnml_l_pos(ctx), left ? "left" : "right"); exit(1); }
+  }
+  // the network afterwards: cores come back with consistent bonds
+  size_t need = 0;
+  OK(tnml_cores_size(ctx, &need));
+  std::vector<float> back(need);
+  std::vector<int> bond2(c.N - 1);
+  int lp = -1;
+  OK(tnml_get_cores(ctx, back.data(), need, bond2.data(), &lp));
+  for (int i = 0; i < c.N - 1; ++i)
+    if (bond2[i] < 1 || bond2[i] > (c.M > D * c.L ? c.M : D * c.L)) { fprintf(stderr, "%s: bond %d = %d\n", c.name, i, bond2[i]); exit(1); }
+  // prediction on a batch of another size (buffers grow), then teardown
+  std::vector<float> Xp((size_t)(c.b / 2 + 3) * c.N * D, 0.25f), fp((size_t)c.L * (c.b / 2 + 3));
+  OK(tnml_predict(ctx, Xp.data(), c.b / 2 + 3, fp.data()));
+  OK(tnml_destroy(ctx));
+  printf("planned %-28s mode %d: %d sweeps ok\n", c.name, mode, c.sweeps);
+  fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+  const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  // BASELINE.json's single-GPU configurations at their true sizes, both directions (two sweeps), plus ragged small shapes
+  std::vector<Cfg> cfgs = {
+      {"c2 bond 10 b 1000", 784, 10, 1000, 2, TNML_TRUNC_FIXED, 2},
+      {"c3 bond 20 b 5000", 784, 20, 5000, 2, TNML_TRUNC_FIXED, 2},
+      {"c5 bond 50 L 10 b 5000", 784, 50, 5000, 10, TNML_TRUNC_FIXED, 2},
+      {"c3 reference policy", 784, 20, 5000, 2, TNML_TRUNC_REFERENCE, 3},
+      {"ragged N 25 bond 12 L 3", 25, 12, 77, 3, TNML_TRUNC_FIXED, 2},
+      {"tiny N 3 bond 3", 3, 3, 9, 2, TNML_TRUNC_REFERENCE, 2},
+      {"bond 64 L 3 (largest)", 18, 64, 200, 3, TNML_TRUNC_FIXED, 2},
+  };
+  for (size_t i = 0; i < cfgs.size(); ++i) {
+    if (quick && cfgs[i].N == 784 && cfgs[i].M != 10) continue;
+    run(cfgs[i], 0);
+    if (cfgs[i].M <= 20) { run(cfgs[i], 1); run(cfgs[i], 2); run(cfgs[i], 4); }
+    if (cfgs[i].N < 100 || cfgs[i].M == 10) run(cfgs[i], 3);
+  }
+  san_stub_report();
+  if (san_stub_launches("sweep_persist") < 1 || san_stub_launches("step_pipe_kernel") < 1 || san_stub_launches("big_jacobi") < 1 ||
+      san_stub_launches("narrow_step_kernel") < 1) {
+    fprintf(stderr, "a launch path was never taken\n");
+    return 1;
+  }
+  printf("host planning under ASan + UBSan: ok\n");
+  return 0;
+}

@@ -150,7 +150,8 @@ __host__ __device__ inline WidePipeSmem wide_pipe_carve(float *base, const WP &p
 }
 inline size_t wide_pipe_lds_bytes(const WidePipeParams &p) {
   const WidePipeDims d = wide_pipe_dims(p);
-  return wide_pipe_carve(nullptr, p, d).floats * sizeof(float) + 16;
+  alignas(16) static float origin[4];                 // only distances from it are used (arithmetic on a null pointer is undefined)
+  return wide_pipe_carve(origin, p, d).floats * sizeof(float) + 16;
 }
 constexpr int kPipeMaxZT = 4;           // 16 x 16 tiles of Z a wave accumulates in registers
 // number of 16 x 16 tiles of Z_l over all labels: must not exceed 16 waves x kPipeMaxZT

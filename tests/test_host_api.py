@@ -178,14 +178,23 @@ def test_random_init_matches_reference_draw_order():
         np.testing.assert_array_equal(a, b)
 
 
-def test_host_arithmetic_under_sanitizers():
-    """csrc/Makefile target `san`: the library's pure host arithmetic (truncation ranks, layout permutations: host_plan.inc,
-    the same text tnml_api.hip includes) compiled with -fsanitize=address,undefined and run over a grid of shapes."""
+def test_host_side_under_sanitizers():
+    """csrc/Makefile target `san`, both halves under -fsanitize=address,undefined:
+      * the pure host arithmetic (truncation ranks, layout permutations: host_plan.inc) over a grid of shapes;
+      * the WHOLE host side of the library -- tnml_api.hip and the launch wrappers of kernels_*.hip, built --cuda-host-only --
+        against the stand-in HIP / RCCL runtime of csrc/san/hip_stub.cpp, which checks every copy and the argument block of
+        every launch (pointers AND the extents the kernels touch) against its allocation registry: whole sweeps of C2, C3
+        and C5 at their true sizes in both directions through the C ABI, persistent / per-step / classic / large-tensor
+        paths, ragged and tiny chains, bond 64 (csrc/san/plan_san_main.cpp)."""
     import shutil
     import subprocess
-    if shutil.which('g++') is None:
-        pytest.skip('no g++')
+    if shutil.which('g++') is None or not os.path.exists('/opt/rocm/bin/hipcc'):
+        pytest.skip('no g++ / hipcc')
     csrc = os.path.join(ROOT, 'tensornetworkforml_amd', 'csrc')
-    out = subprocess.run(['make', '-C', csrc, 'san'], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stdout + out.stderr
+    out = subprocess.run(['make', '-C', csrc, '-j4', 'san'], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert 'sanitizer test ok' in out.stdout
+    assert 'host planning under ASan + UBSan: ok' in out.stdout
+    import re
+    m = re.search(r'san-stub: (\d+) launches checked \((\d+) kernels\), (\d+) pointer extents checked, 0 live allocations', out.stdout)
+    assert m and int(m.group(1)) > 50000 and int(m.group(2)) >= 25 and int(m.group(3)) > 10 ** 6, out.stdout[-2000:]
