@@ -467,29 +467,34 @@ def test_persistent_sweep_matches_per_step_launches_and_oracle(policy, M, N, b, 
             ctx.forward()
             met, f_d = ctx.sweep(left_dir, N - 1, True, kw['lr'], kw['weight_dec'], True, kw['act_fn'], kw['loss_fn'], kw['T'], policy)
             res.append((met, f_d))
-            worst['f_vs_oracle'] = max(worst.get('f_vs_oracle', 0), relerr(f_d, f_o))
+            worst['f_vs_oracle%d' % sw] = max(worst.get('f_vs_oracle%d' % sw, 0), relerr(f_d, f_o))
             worst['acc'] = max(worst.get('acc', 0), np.abs(met[:, 0] - np.array(vh[0])).max() * b)
             worst['mae'] = max(worst.get('mae', 0), np.abs(met[:, 1] - np.array(vh[1])).max())
             _, bond_d, lp = ctx.get_cores()
             assert list(bond_d) == list(st.bond) and lp == st.l_pos
         # the two device paths: the same sums in another association order
-        worst['f_paths'] = max(worst.get('f_paths', 0), relerr(res[0][1], res[1][1]))
+        worst['f_paths%d' % sw] = relerr(res[0][1], res[1][1])
         assert np.abs(res[0][0][:, 0] - res[1][0][:, 0]).max() <= 1.0 / b + 1e-6
         assert np.abs(res[0][0][:, 1] - res[1][0][:, 1]).max() < 2e-4
         np.testing.assert_array_equal(res[0][1], res[2][1])       # the same arithmetic in one kernel or three
         np.testing.assert_array_equal(res[0][0], res[2][0])
     print('persistent sweep', policy, M, N, b, L, {k: '%.2e' % v for k, v in worst.items()})
-    assert worst['f_vs_oracle'] < 2e-3      # observed <= 2.6e-4 (a whole sweep of an untrained chain, from a common start)
-    assert worst['acc'] <= 2.0 + 1e-3       # samples
-    assert worst['mae'] < 2e-3
-    assert worst['f_paths'] < 5e-4          # observed <= 6e-5
+    # The first sweep of a fresh network does not amplify rounding; the second does even from a common start (bond 20, N = 48:
+    # device vs oracle 1.5e-2, the two device forms 4.9e-3 apart after its 47 steps -- test_float32_rounding_is_amplified_by_
+    # the_sweep_dynamics measures the same on the oracle alone), so there f is only bounded and the per-step metrics carry the
+    # comparison: accuracy of every step within one sample, MAE within 2.5e-6.
+    assert worst['f_vs_oracle0'] < 1e-5 and worst['f_paths0'] < 1e-5      # observed <= 1e-6 / 9e-7 over the five cases
+    assert worst['f_vs_oracle1'] < 1e-1 and worst['f_paths1'] < 5e-2
+    assert worst['acc'] <= 1.0 + 1e-3       # samples
+    assert worst['mae'] < 3e-5
     # the persistent context made one launch per sweep, the other one N - 1 (+ the launch that starts a sweep)
     assert ctxs[0].counters()['launches'] == 2 and ctxs[0].counters()['sweep_steps'] == 2 * (N - 1) and ctxs[2].counters()['launches'] == 2
     assert ctxs[1].counters()['launches'] >= 2 * (N - 1)
     p2 = rng.random((b, N))
     X2 = np.stack([np.sin(np.pi * p2 / 2), np.cos(np.pi * p2 / 2)], -1).astype(np.float32)
-    f2 = mo.forward(st, X2.astype(np.float64))
-    for ctx in ctxs:
+    for ctx in ctxs:                                  # the network function on fresh input, each context against its own cores
+        cores_d, _, lp = ctx.get_cores()
+        f2 = mo.forward(mo.MPSState(N, D, L, M, [c.astype(np.float64) for c in cores_d], l_pos=int(lp)), X2.astype(np.float64))
         ctx.set_input(X2, y)
-        assert relerr(ctx.forward(), f2) < 5e-3
+        assert relerr(ctx.forward(), f2) < 2e-5       # observed <= 2e-6
         ctx.close()
