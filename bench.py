@@ -155,6 +155,7 @@ def main():
     ap.add_argument('--pipe-tiles', type=int, default=0, help='sample tiles per batch-side workgroup on steps with a long SVD (tnml_set_step_pipeline(ctx, n), n >= 2)')
     ap.add_argument('--sync-interval', type=int, default=0, help='drain the stream every so many sweep steps (runs under rocprofv3 --pmc)')
     ap.add_argument('--check-launches', action='store_true', help='read the launch status back after every kernel launch')
+    ap.add_argument('--no-comm-overlap', action='store_true', help='multi-GPU: one fused launch per step with the all-reduce between launches (round 2) instead of update side / batch side + all-reduce on two streams')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -175,7 +176,18 @@ def main():
     ctx = _hip.Context(N, D, L, M, b, device=local_rank)
     if args.svd_stop is not None:
         ctx.set_svd_stop(args.svd_stop)
-    tdist.attach_comm(ctx, rank, world)
+    # RCCL prints a version banner on file descriptor 1 when a communicator is created; this program's stdout is ONE JSON line
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        tdist.attach_comm(ctx, rank, world)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    if args.no_comm_overlap:
+        ctx.set_comm_overlap(False)
     if args.sync_interval:
         ctx.set_sync_interval(args.sync_interval)
     if args.check_launches:
@@ -282,6 +294,9 @@ def main():
     ctx.set_input(*batches[0])
     ctx.synchronize()
     h2d_ms = 1e3 * (time.perf_counter() - t0)
+    # the exchange of a multi-GPU step on its own: one all-reduce of the pre-gradient message (collective: every rank calls it)
+    z_floats = min((M * D) * D * D * M * L, 2 * M * D * D * M * L) + 4
+    allreduce_us = ctx.comm_probe(z_floats) if (world > 1 or os.environ.get('TNML_FORCE_COMM') == '1') else None
     # validity: one more pass handing back metrics and f; non-finite values raise inside the library
     met, f = one_pass(want=True)
     finite = bool(np.isfinite(f).all() and np.isfinite(met).all())
@@ -320,7 +335,11 @@ def main():
         'finite': finite,
         'breakdown': {'forward_ms': fwd_ms, 'select_batch_ms': sel_ms, 'h2d_batch_ms': h2d_ms,
                       'sweep_only_steps_per_s': sweep_steps / max(1e-3 * main_run['sweep_ms'], 1e-9),
-                      'steps_per_s_incl_h2d': (N - 1) / (dt / args.steps + 1e-3 * h2d_ms)},
+                      'steps_per_s_incl_h2d': (N - 1) / (dt / args.steps + 1e-3 * h2d_ms),
+                      # multi-GPU: device time of ONE all-reduce of the step's message (%d floats) issued back to back on the
+                      # exchange stream; inside a sweep it runs beside the SVD of the step (tnml_set_comm_overlap)
+                      'allreduce_us': allreduce_us, 'allreduce_floats': z_floats if allreduce_us is not None else None,
+                      'comm_overlap': (not args.no_comm_overlap) if allreduce_us is not None else None},
         'final_accuracy': float(met[-1, 0]),
         # the library's own account of the timed passes (tnml_get_counters: from the bond dimensions of every step that ran)
         'counters': main_run['counters'],

@@ -83,6 +83,13 @@ int tnml_synchronize(tnml_ctx *ctx);
 /* 128-byte RCCL unique id, created on rank 0 and handed to every rank by the caller. */
 int tnml_comm_unique_id(void *uid128);
 int tnml_comm_init(tnml_ctx *ctx, int rank, int nranks, const void *uid128);
+/* With a communicator the pipelined step is launched in two parts -- update side on the context's stream, batch side on a second
+ * stream followed by the all-reduce of the pre-gradient -- so that the exchange travels beside the SVD of the step instead of
+ * behind it (on = 1, default).  on = 0: one fused launch per step with the all-reduce between launches (round 2). */
+int tnml_set_comm_overlap(tnml_ctx *ctx, int on);
+/* measurement: mean device time (us) of one all-reduce of n_floats floats on the exchange stream over `reps` back-to-back calls
+ * (collective: every rank calls it; 0 without a communicator; needs one sweep before it) */
+int tnml_comm_probe(tnml_ctx *ctx, int n_floats, int reps, double *us_per_allreduce);
 
 /* ---- parameters ------------------------------------------------------------------------- */
 /* replaces assignments to Network.As / Network.l_pos */

@@ -1133,6 +1133,10 @@ void launch_step_pipe(const NarrowParams &p, const WidePipeParams &w, size_t lds
   hipLaunchKernelGGL(step_pipe_kernel, dim3(grid), dim3(kNarrowThreads), lds_bytes, st, p, w);
 }
 
+void launch_step_pipe_update(const NarrowParams &p, const WidePipeParams &w, size_t lds_bytes, hipStream_t st) {
+  hipLaunchKernelGGL(step_pipe_kernel, dim3(w.wg0), dim3(kNarrowThreads), lds_bytes, st, p, w);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Persistent sweep: ONE launch per sweep (single GPU, every step in the in-LDS regime, bond dimensions known in advance).
 //   workgroup 0      update + SVD of step k, k = 0 .. n_steps-1 (narrow_body in its persistent mode)

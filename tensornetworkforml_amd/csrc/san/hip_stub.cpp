@@ -34,7 +34,7 @@ static std::map<std::string, long> &launch_map() { static auto *m = new std::map
 #define g_alloc alloc_map()
 #define g_kernels kernel_map()
 #define g_launches launch_map()
-static long g_checked_ptrs = 0;
+static long g_checked_ptrs = 0, g_allreduces = 0;
 static const char *g_ctx = "";
 
 [[noreturn]] static void die(const char *fmt, ...) {
@@ -327,6 +327,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) { free(c); return ncclSuccess; }
 const char *ncclGetErrorString(ncclResult_t) { return "rccl (stub)"; }
 ncclResult_t ncclAllReduce(const void *s, void *d, size_t count, ncclDataType_t t, ncclRedOp_t, ncclComm_t, hipStream_t) {
   g_ctx = "ncclAllReduce";
+  ++g_allreduces;
   const size_t el = t == ncclFloat ? 4 : (t == ncclDouble ? 8 : 4);
   need(s, count * el, "send buffer"); need(d, count * el, "receive buffer");
   if (s != d) memmove(d, s, count * el);
@@ -341,6 +342,7 @@ void san_stub_report(void) {
   printf("san-stub: %ld launches checked (%zu kernels), %ld pointer extents checked, %zu live allocations\n", total, g_launches.size(), g_checked_ptrs, g_alloc.size());
   for (auto &kv : g_launches) printf("    %-60s %ld\n", kv.first.c_str(), kv.second);
 }
+long san_stub_allreduces(void) { return g_allreduces; }
 long san_stub_launches(const char *substr) {
   long n = 0;
   for (auto &kv : g_launches) if (kv.first.find(substr) != std::string::npos) n += kv.second;

@@ -10,6 +10,7 @@
 
 extern "C" void san_stub_report(void);
 extern "C" long san_stub_launches(const char *substr);
+extern "C" long san_stub_allreduces(void);
 
 #define OK(call)                                                                              \
   do {                                                                                        \
@@ -55,6 +56,14 @@ static void run(const Cfg &c, int mode) {
     case 2: OK(tnml_set_step_pipeline(ctx, 0)); break;      // classic launch sequence
     case 3: OK(tnml_set_narrow_path(ctx, 1)); OK(tnml_set_persistent(ctx, 0)); break;   // large-tensor path everywhere
     case 4: OK(tnml_set_persistent(ctx, 2)); break;         // persistent, one kernel per role
+    case 5: case 6: {                                       // one-rank communicator: update side / batch side + all-reduce on two streams (5), fused (6)
+      unsigned char uid[128];
+      setenv("TNML_FORCE_COMM", "1", 1);
+      OK(tnml_comm_unique_id(uid));
+      OK(tnml_comm_init(ctx, 0, 1, uid));
+      if (mode == 6) OK(tnml_set_comm_overlap(ctx, 0));
+      break;
+    }
   }
   std::vector<float> f((size_t)c.L * c.b), met((size_t)2 * (c.N - 1));
   double lm = 0;
@@ -101,7 +110,8 @@ int main(int argc, char **argv) {
   for (size_t i = 0; i < cfgs.size(); ++i) {
     if (quick && cfgs[i].N == 784 && cfgs[i].M != 10) continue;
     run(cfgs[i], 0);
-    if (cfgs[i].M <= 20) { run(cfgs[i], 1); run(cfgs[i], 2); run(cfgs[i], 4); }
+    if (cfgs[i].M <= 20) { run(cfgs[i], 1); run(cfgs[i], 2); run(cfgs[i], 4); run(cfgs[i], 5); run(cfgs[i], 6); }
+    else if (cfgs[i].M == 50) run(cfgs[i], 5);
     if (cfgs[i].N < 100 || cfgs[i].M == 10) run(cfgs[i], 3);
   }
   san_stub_report();
@@ -110,6 +120,8 @@ int main(int argc, char **argv) {
     fprintf(stderr, "a launch path was never taken\n");
     return 1;
   }
+  if (san_stub_allreduces() < 5000) { fprintf(stderr, "the communicator path issued only %ld all-reduces\n", san_stub_allreduces()); return 1; }
+  printf("communicator path: %ld all-reduces checked\n", san_stub_allreduces());
   printf("host planning under ASan + UBSan: ok\n");
   return 0;
 }

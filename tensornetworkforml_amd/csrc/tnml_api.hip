@@ -53,6 +53,12 @@ struct tnml_ctx {
   hipEvent_t ev_p0 = nullptr, ev_p2 = nullptr, ev_p3 = nullptr;
   int persist_mode = 1;                      // tnml_set_persistent: 0 per-step launches, 1 one kernel per sweep (default), 2 one kernel per role
   hipEvent_t ev_main = nullptr, ev_prep = nullptr;
+  // communicator path of the pipelined step: update side on `stream`, batch side + all-reduce of the pre-gradient on `stream2`
+  // (ev_upd[i]: an update launch has ended; ev_bat[i]: a batch-side launch and the exchange behind it have ended)
+  hipEvent_t ev_upd[2] = {nullptr, nullptr}, ev_bat[2] = {nullptr, nullptr};
+  int split_upd = 0, split_bat = 0;          // index of the event recorded last
+  bool split_pending = false;                // stream2 holds batch-side work `stream` has not waited for yet
+  bool split_enabled = true;                 // tnml_set_comm_overlap
   hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
   // host bookkeeping
   std::vector<int> bond;
@@ -226,6 +232,10 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipEventCreateWithFlags(&c->ev_p3, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_upd[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_bat[i], hipEventDisableTiming));
+  }
   HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipEventCreate(&c->pev0)); HIP_TRY(hipEventCreate(&c->pev1));
   c->core_stride = (size_t)Mmax * D * Mmax;
@@ -305,6 +315,7 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->pev1) (void)hipEventDestroy(c->pev1);
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
   if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+  for (int i = 0; i < 2; ++i) { if (c->ev_upd[i]) (void)hipEventDestroy(c->ev_upd[i]); if (c->ev_bat[i]) (void)hipEventDestroy(c->ev_bat[i]); }
   if (c->ev_p0) (void)hipEventDestroy(c->ev_p0);
   if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
   if (c->ev_p3) (void)hipEventDestroy(c->ev_p3);
@@ -875,6 +886,16 @@ static bool wide_pipe_fits(const tnml_ctx *c, const WidePipeParams &w) {
   return true;
 }
 
+// Communicator path: whatever the batch-side stream still holds (f, environments, the exchanged pre-gradient) has to be complete
+// before the context's stream touches it outside a split step.
+static int split_join(tnml_ctx *c) {
+  if (c->split_pending) {
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_bat[c->split_bat], 0));
+    c->split_pending = false;
+  }
+  return TNML_OK;
+}
+
 // f-part operands for "the step that just ended" seen from relative step index k (k >= 1):
 // fills hp, gp, Hprev, Gprev, x_km1, x_k, Bprev of `w`.
 static void fill_prev_operands(tnml_ctx *c, WideParams &w, int left_dir, int p_prev) {
@@ -1236,7 +1257,63 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
         if (!wide_pipe_fits(c, wpro)) pipe = false; else need_prologue = true;
       }
     }
-    if (pipe) {
+    // Communicator path (batch shards over the ranks): the pre-gradient Z_{k+1} is final ~25 us into a ~57 us step, but behind
+    // a fused launch its all-reduce could only start when the SVD of step k has ended -- on the critical path of every step.
+    // So the step is launched in two parts: the update side (workgroup 0 + slice helpers) on the context's stream, the
+    // batch side on stream2 followed by the all-reduce, which then travels beside the SVD; the next update launch waits
+    // for its event.  Same kernels, same arithmetic as the fused launch (the B_new hand-off is a flag in memory either way).
+    const bool split = pipe && c->comm && c->split_enabled && !c->profile;
+    if (pipe && !split) { int rc = split_join(c); if (rc) return rc; }
+    if (pipe && split) {
+      if (!c->split_pending) {                 // first split step after anything else: stream2 starts behind the context's stream
+        c->split_upd ^= 1;
+        HIP_TRY(hipEventRecord(c->ev_upd[c->split_upd], c->stream));
+      }
+      if (need_prologue) {
+        NarrowParams none{};
+        wpro.wg0 = 0;
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upd[c->split_upd], 0));
+        launch_step_pipe(none, wpro, wide_pipe_lds_bytes(wpro), c->stream2);
+        c->sweep_launches++; c->step_launches++;
+        NCCL_TRY(ncclAllReduce(c->zred, c->zred, wpro.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream2));
+        c->split_bat ^= 1;
+        HIP_TRY(hipEventRecord(c->ev_bat[c->split_bat], c->stream2));
+        c->split_pending = true;
+        if (wpro.do_f) c->f_current = true;
+      }
+      n.fused = 1; n.nred = 0; n.sync = c->sync; n.red_out = nullptr;
+      n.prep_ready = 0;
+      n.wait_count = kD * kD * (h > 8 ? 2 : 1);
+      n.pipe = 1; n.z_first = (k == 0); n.z_rows = wp.hprev * D;
+      n.zsize = (k == 0 ? 1 : n.z_rows) * D * D * g * L;
+      n.zred = c->zred; n.red = c->zred; n.zcore = wp.ext_core;
+      n.flag = c->pipe_cnt + 17; n.token = ++c->token;
+      wp.token = n.token;
+      wp.wg0 = 1 + n.wait_count;
+      const size_t lds_u = std::max(narrow_lds_bytes(h, g, s, L, m), prep_slice_lds_bytes(h, g, s, L));
+      const size_t lds_b = wide_pipe_lds_bytes(wp);
+      if (lds_u > 160 * 1024 || lds_b > 160 * 1024) return fail(TNML_ERR_ARG, "internal: pipelined step needs %zu / %zu bytes of LDS", lds_u, lds_b);
+      // batch side of step k: needs the behind core the update launch of step k-1 left (event), then B_new(k) (flag in memory)
+      const int upd_prev = c->split_upd;
+      HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upd[upd_prev], 0));
+      {
+        NarrowParams none{};
+        WidePipeParams wb = wp;
+        wb.wg0 = 0;
+        launch_step_pipe(none, wb, lds_b, c->stream2);
+      }
+      // update side of step k: needs Z_k summed over the ranks (the exchange enqueued behind the previous batch-side launch)
+      if (c->split_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_bat[c->split_bat], 0));
+      launch_step_pipe_update(n, wp, lds_u, c->stream);
+      c->split_upd ^= 1;
+      HIP_TRY(hipEventRecord(c->ev_upd[c->split_upd], c->stream));
+      if (wp.do_z) NCCL_TRY(ncclAllReduce(c->zred, c->zred, wp.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream2));
+      c->split_bat ^= 1;
+      HIP_TRY(hipEventRecord(c->ev_bat[c->split_bat], c->stream2));
+      c->split_pending = true;
+      c->sweep_launches += 2; c->step_launches++;
+      c->Z_valid = wp.do_z != 0; c->Z_k = k + 1; c->Z_left = left_dir; c->Z_act = act_fn; c->Z_loss = loss_fn; c->Z_T = T;
+    } else if (pipe) {
       if (need_prologue) {
         NarrowParams none{};
         wpro.wg0 = 0;
@@ -1268,6 +1345,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       if (c->comm && wp.do_z) NCCL_TRY(ncclAllReduce(c->zred, c->zred, wp.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
       c->Z_valid = wp.do_z != 0; c->Z_k = k + 1; c->Z_left = left_dir; c->Z_act = act_fn; c->Z_loss = loss_fn; c->Z_T = T;
     } else {
+      { int rc = split_join(c); if (rc) return rc; }
       c->Z_valid = false;
       // ---- wide kernel -----------------------------------------------------------------------
       WideParams w{};
@@ -1382,6 +1460,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     if (c->sync_interval > 0 && (step + 1) % c->sync_interval == 0) HIP_TRY(hipStreamSynchronize(c->stream));
   }
   HIP_TRY(hipGetLastError());
+  { int rc = split_join(c); if (rc) return rc; }
   // the sweep grew the behind stacks: they are the ones valid for the opposite direction now
   if (!l2_flag) {
     c->Ln_valid = c->Rn_valid = false;
@@ -1583,6 +1662,36 @@ extern "C" int tnml_set_trunc_threshold(tnml_ctx *c, double threshold) {
 extern "C" int tnml_set_narrow_path(tnml_ctx *c, int force_large) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   c->force_big = force_large != 0;
+  return TNML_OK;
+}
+
+// mean device time of one all-reduce of `n_floats` floats on the exchange stream, `reps` of them back to back (the message of a C3
+// step is 6404 floats); 0 without a communicator
+extern "C" int tnml_comm_probe(tnml_ctx *c, int n_floats, int reps, double *us_per_allreduce) {
+  if (!c || !us_per_allreduce || n_floats < 1 || reps < 1) return fail(TNML_ERR_ARG, "bad argument");
+  *us_per_allreduce = 0.0;
+  if (!c->comm) return TNML_OK;
+  if ((size_t)n_floats > (size_t)c->zstride) return fail(TNML_ERR_ARG, "probe message of %d floats exceeds the pre-gradient buffer (%d)", n_floats, c->zstride);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream2));
+  // (gslabs: scratch of the same size class, not live between sweeps)
+  float *buf = c->gslabs ? c->gslabs : c->zslabs;
+  if (!buf) return fail(TNML_ERR_STATE, "no pipelined-step buffers yet: run a sweep first");
+  for (int w = 0; w < 3; ++w) NCCL_TRY(ncclAllReduce(buf, buf, n_floats, ncclFloat, ncclSum, c->comm, c->stream2));
+  HIP_TRY(hipEventRecord(c->ev0, c->stream2));
+  for (int r = 0; r < reps; ++r) NCCL_TRY(ncclAllReduce(buf, buf, n_floats, ncclFloat, ncclSum, c->comm, c->stream2));
+  HIP_TRY(hipEventRecord(c->ev1, c->stream2));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *us_per_allreduce = 1e3 * ms / reps;
+  return TNML_OK;
+}
+
+extern "C" int tnml_set_comm_overlap(tnml_ctx *c, int on) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  c->split_enabled = on != 0;
   return TNML_OK;
 }
 

@@ -161,6 +161,8 @@ inline int wide_pipe_ztiles(const WidePipeParams &p) {
 }
 // grid = w.wg0 + w.nwide workgroups of 1024 threads (kernels_narrow.hip)
 void launch_step_pipe(const NarrowParams &p, const WidePipeParams &w, size_t lds_bytes, hipStream_t st);
+// the update side alone: workgroups 0 .. w.wg0 - 1 (the batch-side workgroups of the same step are launched on another stream with w.wg0 = 0)
+void launch_step_pipe_update(const NarrowParams &p, const WidePipeParams &w, size_t lds_bytes, hipStream_t st);
 
 // persistent sweep (kernels_narrow.hip: sweep_persist_kernel): what a helper workgroup needs for step k, and one record per step
 struct PersistHelperParams {

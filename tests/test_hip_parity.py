@@ -248,6 +248,60 @@ def test_rccl_path_single_rank(monkeypatch):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
 
 
+def test_rccl_exchange_beside_the_svd(monkeypatch):
+    """With a communicator the pipelined step is launched in two parts -- update side on the context's stream, batch side +
+    all-reduce of the pre-gradient on a second stream (tnml_set_comm_overlap, default on) -- so that the exchange starts when
+    Z is final (~25 us into a ~57 us step) instead of after the SVD.  On one GPU (TNML_FORCE_COMM=1: a one-rank communicator):
+      * bit-equal f, metrics and cores to the fused launch with the all-reduce between launches and to the communicator-free
+        per-step launches (the same kernels and the same arithmetic; the one-rank sum is the identity);
+      * the device time of a C3-shaped sweep against the communicator-free per-step launches: the two cross-queue dependencies of
+        a split step (update launch waits for the exchange, batch-side launch waits for the previous update launch) cost
+        10 us per step on one GPU (65.2 -> 75.1 us; the fused form with a one-rank, i.e. empty, all-reduce: 65.2 us).  Against
+        that the fused form pays the whole all-reduce on the critical path of every step: the split form wins as soon as one
+        exchange takes more than those 10 us (bench.py reports it: breakdown.allreduce_us)."""
+    from tensornetworkforml_amd import dist as tdist
+    N, M, b, L, D = 96, 20, 5000, 2, 2
+    rng = np.random.default_rng(5)
+    p = rng.random((b, N)) * (rng.random((b, N)) > 0.8)
+    X = np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32)
+    y = rng.integers(0, L, b)
+    cores = mo.random_cores(N, M, D, L, rng=rng, scale=M * 0.5 * 0.64 * D)
+    st = mo.MPSState(N, D, L, M, cores)
+    mo.calibrate(st, X[:500].astype(np.float64))
+    cores32 = [c.astype(np.float32) for c in st.cores]
+    hp = (1e-3, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
+    res, us = {}, {}
+    for name, force, overlap in (('no communicator', '0', True), ('fused + all-reduce between launches', '1', False), ('two streams', '1', True)):
+        monkeypatch.setenv('TNML_FORCE_COMM', force)
+        ctx = make_ctx(N, D, L, M, cores32, 0, X, y)
+        ctx.set_persistent(0)
+        tdist.attach_comm(ctx, 0, 1)
+        ctx.set_comm_overlap(overlap)
+        outs = []
+        for sw in range(4):
+            ctx.forward(want_f=False)
+            met, f = ctx.sweep(ctx.l_pos == N - 1, N - 1, True, *hp)
+            outs.append((met, f))
+        outs.append(tuple(ctx.get_cores()[0]))
+        # device time of two more sweeps (HIP events on the context's stream around each tnml_sweep call; nothing waits inside)
+        ctx.profile_reset()
+        ctx.profile_enable(2)
+        for sw in range(4):
+            ctx.forward(want_f=False)
+            ctx.sweep(ctx.l_pos == N - 1, N - 1, True, *hp, want_metrics=False, want_f=False)
+        ms, _ = ctx.profile_get(4)
+        us[name] = 1e3 * ms / (4 * (N - 1))
+        res[name] = outs
+        ctx.close()
+    print('device time per step (us):', {k: round(v, 2) for k, v in us.items()})
+    for other in ('fused + all-reduce between launches', 'two streams'):
+        for a, b_ in zip(res['no communicator'], res[other]):
+            for x, y_ in zip(a, b_):
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(y_))
+    assert us['two streams'] - us['no communicator'] < 15.0, us        # observed 9.9
+    assert abs(us['fused + all-reduce between launches'] - us['no communicator']) < 3.0, us
+
+
 # default threshold: worst product error observed between 2.6e-6 and 2.6e-5 over builds that differ only in the rounding
 # order of float64 sums (the worst step of two late sweeps is a tail statistic of a chaotic trajectory)
 @pytest.mark.parametrize('stop2,tol', [(None, 5e-5), (1e-4, 1e-3), (1e-8, 5e-6)])

@@ -71,11 +71,11 @@ for ps in range(P + 2):
         worst['sig_rel_kept'] = max(worst['sig_rel_kept'], (np.abs(sig[:m] - S[:m]) / S[:m]).max())
         worst['prod'] = max(worst['prod'], np.abs(matricize(prod, left) - best).max() / np.abs(best).max())
         sweeps.append((int(sc[3]), int(sc[4])))
-        dump.append((Bm.astype(np.float32), m, int(sc[3])))
+        dump.append((Bm.astype(np.float32), m, int(sc[3]), int(sc[55]) if len(sc) > 55 else -1))
     ctx.debug_enable(False)
     os.makedirs('gpurun_out', exist_ok=True)
     np.savez('gpurun_out/svd_mats_%s.npz' % ('left' if left else 'right'), **{'B%d' % i: d[0] for i, d in enumerate(dump)},
-             m=np.array([d[1] for d in dump]), sweeps=np.array([d[2] for d in dump]))
+             m=np.array([d[1] for d in dump]), sweeps=np.array([d[2] for d in dump]), rounds=np.array([d[3] for d in dump]))
     print('checked pass (%s): sweeps (count, n) %s' % ('left' if left else 'right', sweeps[:8] + ['...'] + sweeps[len(sweeps) // 2:len(sweeps) // 2 + 3]))
     print('   worst |sigma - lapack| / sigma_max = %.2e ; worst relative error of a kept sigma = %.2e ; '
           'worst |A.C - best rank-m| / max = %.2e' % (worst['sig_abs'], worst['sig_rel_kept'], worst['prod']))
