@@ -107,15 +107,18 @@ def cpu_baseline(N, M, D, L, b, n_steps, seed):
 def cpu_baseline_reference_form(N, M, D, L, st, f, y1h, budget_s):
     """B1 / B2 / B3 of BASELINE.md section 3: the step in the reference's own computational form
     (oracle/mps_reference_form.py: broadcast-multiply-sum contractions, L2 norm environments rebuilt from the chain ends
-    at every step, float64), continued from the mid-chain state the B4 timing left behind.  A few steps each, bounded by
+    at every step, float64).  B3 and the `first_sweep` forms continue from the mid-chain fixed-bond state the B4 timing left
+    behind; the `steady_state` forms step a chain whose bonds are all 2 (what the reference's rule leaves after one sweep:
+    BASELINE.md section 2 quotes 4.2 steps/s for it).  A few steps each, bounded by
     `budget_s` seconds in total; rates are sweep steps per second of the step alone (the reference's forward, 84-112 s at
     this shape in the survey container, is not included)."""
     import copy
+    from oracle import mps_oracle as mo
     from oracle import mps_reference_form as rf
     out = {}
     t_end = time.perf_counter() + budget_s
-    for tag, trunc, l2 in (('B3_fixed_bond_L2', 'fixed', True), ('B1_reference_truncation_L2', 'reference', True),
-                           ('B2_reference_truncation_noL2', 'reference', False)):
+    for tag, trunc, l2 in (('B3_fixed_bond_L2', 'fixed', True), ('B1_reference_truncation_L2_first_sweep', 'reference', True),
+                           ('B2_reference_truncation_noL2_first_sweep', 'reference', False)):
         s2 = copy.deepcopy(st)
         s2.Ln, s2.Rn = {}, {}
         ff = f.copy()
@@ -126,11 +129,29 @@ def cpu_baseline_reference_form(N, M, D, L, st, f, y1h, budget_s):
             t0 = time.perf_counter()
             ff = rf.sweep_step(s2, ff, y1h, 1e-3, 1e-3, l2, False, 'softmax', 'full_cross_ent', 0.1, trunc)
             times.append(time.perf_counter() - t0)
-        # the first step of the reference-truncation variants still sees the fixed-bond state (behind bond 20); from the
-        # second on the behind bond is the reference's 2
+        # the reference-truncation variants continue from the fixed-bond state: the rule keeps m = left bond, so the bond
+        # behind stays at its incoming value (20 at c3) -- the regime of the reference's FIRST sweep over a bond-M network
         use = times[1:] if len(times) > 1 else times
         out[tag] = {'steps_per_s': 1.0 / float(np.mean(use)), 'ms_per_step': 1e3 * float(np.mean(use)), 'steps_timed': len(use),
                     'behind_bond': int(s2.ml(s2.l_pos)), 'ahead_bond': int(s2.mr(min(s2.l_pos + 1, N - 1)))}
+    # the reference's STEADY state: after its first sweep every bond is 2 (m = left bond, 2 at the chain start); a chain of
+    # bond-2 cores, environments from the oracle's forward, the first steps of a right sweep
+    Xb = st.X
+    rng = np.random.default_rng(7)
+    for tag, l2 in (('B1_reference_truncation_L2_steady_state', True), ('B2_reference_truncation_noL2_steady_state', False)):
+        if time.perf_counter() > t_end + 10.0:
+            break
+        s3 = mo.MPSState(N, D, L, 2, mo.random_cores(N, 2, D, L, rng=rng, scale=2 * 0.5 * 0.64 * D))
+        mo.calibrate(s3, Xb[:256])
+        ff = mo.forward(s3, Xb)
+        times = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            ff = rf.sweep_step(s3, ff, y1h, 1e-3, 1e-3, l2, False, 'softmax', 'full_cross_ent', 0.1, 'reference')
+            times.append(time.perf_counter() - t0)
+        use = times[1:]
+        out[tag] = {'steps_per_s': 1.0 / float(np.mean(use)), 'ms_per_step': 1e3 * float(np.mean(use)), 'steps_timed': len(use),
+                    'behind_bond': int(s3.ml(s3.l_pos)), 'ahead_bond': int(s3.mr(min(s3.l_pos + 1, N - 1)))}
     return out
 
 
@@ -477,7 +498,7 @@ def main():
                           'forward not included',
                 'forms': rf,
                 'gpu_over_B3': steps_per_s / rf['B3_fixed_bond_L2']['steps_per_s'],
-                'gpu_over_B1': steps_per_s / rf['B1_reference_truncation_L2']['steps_per_s']}
+                'gpu_over_B1_first_sweep': steps_per_s / rf['B1_reference_truncation_L2_first_sweep']['steps_per_s']}
     drain_whole()
     if 'roofline' in out and whole['launches'] and all_pipe:
         out['roofline']['step_kernel_avg_us_hip_events_whole_run'] = 1e3 * whole['ms'] / whole['launches']
