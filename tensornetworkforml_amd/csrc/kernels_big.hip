@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdio>
 
+#include <type_traits>
 #include "tnml_internal.h"
 #include "jacobi_device.h"
 
@@ -34,9 +35,21 @@ __global__ __launch_bounds__(kBT) void big_merge_kernel(NarrowParams p, float *_
     const int dk = q % D, h_ = q / D;
     const float *la = p.lab.base + h_ * p.lab.s_in + dk * p.lab.s_d + l;
     const float *pl = p.pl.base + dk1 * p.pl.s_d + g_ * p.pl.s_out;
-    double acc = 0.0;
-    for (int k = 0; k < s; ++k) acc += (double)la[k * p.lab.s_out] * (double)pl[k * p.pl.s_in];
-    Bf[e] = (float)acc;
+    // (the launch has ~1.5 waves per SIMD: a dependent load + FMA per iteration made this kernel one memory latency per k -- 16 us for
+    //  s = 50.  Eight loads in flight and four accumulators: the sum is re-associated, in float64)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int k = 0;
+    for (; k + 8 <= s; k += 8) {
+      float lv[8], pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { lv[u] = la[(k + u) * p.lab.s_out]; pv[u] = pl[(k + u) * p.pl.s_in]; }
+      a0 = fma((double)lv[0], (double)pv[0], a0); a1 = fma((double)lv[1], (double)pv[1], a1);
+      a2 = fma((double)lv[2], (double)pv[2], a2); a3 = fma((double)lv[3], (double)pv[3], a3);
+      a0 = fma((double)lv[4], (double)pv[4], a0); a1 = fma((double)lv[5], (double)pv[5], a1);
+      a2 = fma((double)lv[6], (double)pv[6], a2); a3 = fma((double)lv[7], (double)pv[7], a3);
+    }
+    for (; k < s; ++k) a0 = fma((double)la[k * p.lab.s_out], (double)pl[k * p.pl.s_in], a0);
+    Bf[e] = (float)((a0 + a1) + (a2 + a3));
   }
 }
 
@@ -46,8 +59,19 @@ __global__ __launch_bounds__(kBT) void big_l2_T_kernel(NarrowParams p, const flo
   for (int e = blockIdx.x * kBT + threadIdx.x; e < p.bsize; e += gridDim.x * kBT) {
     const int rest = e % RW, e_ = e / RW;
     double acc = 0.0;
-    if (p.Nh) { for (int a = 0; a < h; ++a) acc += p.Nh[a * h + e_] * (double)Bf[(size_t)a * RW + rest]; }
-    else acc = (double)Bf[e];
+    if (p.Nh) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int a = 0;
+      for (; a + 8 <= h; a += 8) {
+        double nv[8]; float bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { nv[u] = p.Nh[(a + u) * h + e_]; bv[u] = Bf[(size_t)(a + u) * RW + rest]; }
+        a0 = fma(nv[0], (double)bv[0], a0); a1 = fma(nv[1], (double)bv[1], a1); a2 = fma(nv[2], (double)bv[2], a2); a3 = fma(nv[3], (double)bv[3], a3);
+        a0 = fma(nv[4], (double)bv[4], a0); a1 = fma(nv[5], (double)bv[5], a1); a2 = fma(nv[6], (double)bv[6], a2); a3 = fma(nv[7], (double)bv[7], a3);
+      }
+      for (; a < h; ++a) a0 = fma(p.Nh[a * h + e_], (double)Bf[(size_t)a * RW + rest], a0);
+      acc = (a0 + a1) + (a2 + a3);
+    } else acc = (double)Bf[e];
     T[e] = acc;
   }
 }
@@ -66,8 +90,19 @@ __global__ __launch_bounds__(kBT) void big_wd_kernel(NarrowParams p, const float
       const int l = e % L, q = e / L;
       const int f_ = q % g, i = q / g;
       double gv = 0.0;
-      if (p.Ng) { for (int c = 0; c < g; ++c) gv += T[((size_t)i * g + c) * L + l] * p.Ng[c * g + f_]; }
-      else gv = T[e];
+      if (p.Ng) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int c = 0;
+        for (; c + 8 <= g; c += 8) {
+          double tv[8], nv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { tv[u] = T[((size_t)i * g + c + u) * L + l]; nv[u] = p.Ng[(c + u) * g + f_]; }
+          a0 = fma(tv[0], nv[0], a0); a1 = fma(tv[1], nv[1], a1); a2 = fma(tv[2], nv[2], a2); a3 = fma(tv[3], nv[3], a3);
+          a0 = fma(tv[4], nv[4], a0); a1 = fma(tv[5], nv[5], a1); a2 = fma(tv[6], nv[6], a2); a3 = fma(tv[7], nv[7], a3);
+        }
+        for (; c < g; ++c) a0 = fma(T[((size_t)i * g + c) * L + l], p.Ng[c * g + f_], a0);
+        gv = (a0 + a1) + (a2 + a3);
+      } else gv = T[e];
       l2 += bv * gv;
       wdterm = 2.0 * (double)p.wd * gv;
     } else {
@@ -252,6 +287,10 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
     itD11[u] = elem_slot(o1, c1, np); itD12[u] = elem_slot(o1, c2, np);
     itD21[u] = elem_slot(o2, c1, np); itD22[u] = elem_slot(o2, c2, np);
   }
+  // item slots this WAVE runs (wave-uniform: slot u is valid for a prefix of the worker threads)
+  int wave_items = 0;
+#pragma unroll
+  for (int u = 0; u < MAXI; ++u) wave_items += __builtin_amdgcn_readfirstlane(__ballot(itValid[u]) != 0ull ? 1 : 0);
   const double abs2 = kJacobiAbs * kJacobiAbs;
   const bool isParam = tid < np;
   int pa = 0, pb = 1;
@@ -325,27 +364,47 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
           const RotT r = jacobi_rot_f32(na, nb, ng, fmaxf((float)kept2, kept_lo), (float)abs2, (float)a.stop2);
           publish(dCS + ((cur ^ 1) * np + tid) * 4, r, rounds + 1, (size_t)(rounds + 1) * np + tid);
         }
+        // The items of a lane as INDEPENDENT chains: all operands are requested first, the (dependent, 40-cycle) float64 steps of the
+        // items interleave, stores last.  A per-item `if (!valid) continue` made them run one after the other: a round of the
+        // n = 100 matrix (1275 blocks on 960 worker threads: two items on a third of them) cost 2760 cycles.  The number of
+        // item slots a WAVE runs is wave-uniform (items are dealt slot by slot), so waves without a second item skip it with a
+        // scalar branch.
+        auto run_items = [&](auto KC) {
+          constexpr int K = decltype(KC)::value;
+          double2 tq[K], tp[K], r0[K], r1[K];
 #pragma unroll
-        for (int u = 0; u < MAXI; ++u) {
-          if (!itValid[u]) continue;
-          const double2 tq = *reinterpret_cast<const double2 *>(csc + itQ[u]);       // (t, c0) of the column pair
-          const double2 tp = *reinterpret_cast<const double2 *>(csc + itP[u]);       // ... of the row pair
-          const double2 r0 = *reinterpret_cast<const double2 *>(Gc + itSrc[u]);
-          double2 r1 = *reinterpret_cast<const double2 *>(Gc + itSrc[u] + 2);
-          if (itDiag[u]) r1.x = r0.y;
-          // R_P^T . blk . R_Q = cP cQ [[1, -tP], [tP, 1]] . blk . [[1, tQ], [-tQ, 1]]: the tangents act first, the product of the
-          // two refined cosines is formed meanwhile and multiplied in last
-          const double a11 = fma(-tp.x, r1.x, r0.x), a12 = fma(-tp.x, r1.y, r0.y);
-          const double a21 = fma(tp.x, r0.x, r1.x), a22 = fma(tp.x, r0.y, r1.y);
-          const double b11 = fma(-tq.x, a12, a11), b12 = fma(tq.x, a11, a12);
-          const double b21 = fma(-tq.x, a22, a21), b22 = fma(tq.x, a21, a22);
-          const double c00 = tp.y * tq.y, corr = rot_corr(tp.x, tp.y) * rot_corr(tq.x, tq.y);
-          double n11 = (b11 * c00) * corr, n12 = (b12 * c00) * corr, n21 = (b21 * c00) * corr, n22 = (b22 * c00) * corr;
-          if (itDiag[u] && tq.x != 0.0) { n12 = 0.0; n21 = 0.0; }
-          Gn[itD11[u]] = n11; Gn[itD12[u]] = n12;
-          if (!itDiag[u]) Gn[itD21[u]] = n21;
-          Gn[itD22[u]] = n22;
-        }
+          for (int u = 0; u < K; ++u) {
+            tq[u] = *reinterpret_cast<const double2 *>(csc + itQ[u]);       // (t, c0) of the column pair
+            tp[u] = *reinterpret_cast<const double2 *>(csc + itP[u]);       // ... of the row pair
+            r0[u] = *reinterpret_cast<const double2 *>(Gc + itSrc[u]);
+            r1[u] = *reinterpret_cast<const double2 *>(Gc + itSrc[u] + 2);
+            if (itDiag[u]) r1[u].x = r0[u].y;
+          }
+          double n11[K], n12[K], n21[K], n22[K];
+#pragma unroll
+          for (int u = 0; u < K; ++u) {
+            // R_P^T . blk . R_Q = cP cQ [[1, -tP], [tP, 1]] . blk . [[1, tQ], [-tQ, 1]]: the tangents act first, the product of the
+            // two refined cosines is formed meanwhile and multiplied in last
+            const double a11 = fma(-tp[u].x, r1[u].x, r0[u].x), a12 = fma(-tp[u].x, r1[u].y, r0[u].y);
+            const double a21 = fma(tp[u].x, r0[u].x, r1[u].x), a22 = fma(tp[u].x, r0[u].y, r1[u].y);
+            const double b11 = fma(-tq[u].x, a12, a11), b12 = fma(tq[u].x, a11, a12);
+            const double b21 = fma(-tq[u].x, a22, a21), b22 = fma(tq[u].x, a21, a22);
+            const double c00 = tp[u].y * tq[u].y, corr = rot_corr(tp[u].x, tp[u].y) * rot_corr(tq[u].x, tq[u].y);
+            n11[u] = (b11 * c00) * corr; n12[u] = (b12 * c00) * corr; n21[u] = (b21 * c00) * corr; n22[u] = (b22 * c00) * corr;
+            if (itDiag[u] && tq[u].x != 0.0) { n12[u] = 0.0; n21[u] = 0.0; }
+          }
+#pragma unroll
+          for (int u = 0; u < K; ++u) {
+            if (itValid[u]) {
+              Gn[itD11[u]] = n11[u]; Gn[itD12[u]] = n12[u];
+              if (!itDiag[u]) Gn[itD21[u]] = n21[u];
+              Gn[itD22[u]] = n22[u];
+            }
+          }
+        };
+        if (wave_items == 1) run_items(std::integral_constant<int, 1>());
+        else if (wave_items == 2) run_items(std::integral_constant<int, 2>());
+        else if (wave_items == 3) run_items(std::integral_constant<int, 3>());
         // LDS-only barrier: __syncthreads() would also drain the parameter threads' stores to the rotation log (global memory,
         // read by the next kernel) -- a memory round trip per round
         lds_barrier();
@@ -577,10 +636,103 @@ static bool big_launch_done(const char *name, bool check, dim3 grid, dim3 block,
   return true;
 }
 
+// ---- pipelined large-tensor step (round 3): the two small kernels around the batch kernel that runs beside the SVD -----------
+// (1) Behind environment of step k and the (h, d) operand of the pre-gradient Z_{k+1}:
+//       E_k[h'][s]        = sum_{(h, d)} E_{k-1}[h][s] x_{k-1}[s][d] A_{k-1}(h, d, h')                 (Network_class.py:637-652)
+//       P'_k[(h', d')][s] = E_k[h'][s] x_k[s][d']
+//     64 samples per workgroup, the core in LDS (every lane of a wave reads the same element: a broadcast), four groups of
+//     bond indices; plain FMAs: 25 MFLOP, a few microseconds beside a 170 us Jacobi kernel.
+__global__ __launch_bounds__(256) void big_ext_kernel(const float *__restrict__ Eprev, const float *__restrict__ x_km1,
+                                                     const float *__restrict__ x_k, CoreView A, int b_pad,
+                                                     float *__restrict__ Ecur, float *__restrict__ Pk) {
+  extern __shared__ __attribute__((aligned(16))) float sAext[];          // [(h, d)][h' padded to a multiple of 4]
+  const int hp = A.n_in, h = A.n_out, nI = hp * kD, HS = (h + 3) & ~3;
+  for (int e = threadIdx.x; e < nI * HS; e += 256) {
+    const int i = e / HS, o = e - i * HS;
+    sAext[e] = o < h ? A.base[(size_t)(i >> 1) * A.s_in + (i & 1) * A.s_d + (size_t)o * A.s_out] : 0.f;
+  }
+  __syncthreads();
+  // 64 samples x 16 bond indices per workgroup: a lane owns one sample and four consecutive h' (one 16-byte LDS read per core row)
+  const int s = blockIdx.x * 64 + (threadIdx.x & 63), o = blockIdx.y * 16 + 4 * (threadIdx.x >> 6);
+  if (o >= h) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float xm0 = x_km1[(size_t)s * kD], xm1 = x_km1[(size_t)s * kD + 1];
+  for (int hh = 0; hh < hp; ++hh) {
+    const float e = Eprev[(size_t)hh * b_pad + s];
+    const float e0 = e * xm0, e1 = e * xm1;
+    const float4 a0 = *reinterpret_cast<const float4 *>(sAext + (size_t)(2 * hh) * HS + o);
+    const float4 a1 = *reinterpret_cast<const float4 *>(sAext + (size_t)(2 * hh + 1) * HS + o);
+    acc.x = fmaf(e1, a1.x, fmaf(e0, a0.x, acc.x)); acc.y = fmaf(e1, a1.y, fmaf(e0, a0.y, acc.y));
+    acc.z = fmaf(e1, a1.z, fmaf(e0, a0.z, acc.z)); acc.w = fmaf(e1, a1.w, fmaf(e0, a0.w, acc.w));
+  }
+  const float x0 = x_k[(size_t)s * kD], x1 = x_k[(size_t)s * kD + 1];
+  const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (o + u < h) {
+      Ecur[(size_t)(o + u) * b_pad + s] = v[u];
+      Pk[(size_t)(2 * (o + u)) * b_pad + s] = v[u] * x0;
+      Pk[(size_t)(2 * (o + u) + 1) * b_pad + s] = v[u] * x1;
+    }
+}
+
+// (2) The raw gradient of step k+1 from the reduced pre-gradient and the behind core the SVD of step k has just left:
+//       dB_{k+1}[h', c] = sum_{i = (h, d)} A_k(h, d, h') Z_{k+1}[i][c],      c = (d', d'', g, l)                 
+//     one column and eight h' per thread, the core in LDS (16-byte broadcast reads); the four metric slots behind Z are carried
+//     over.  Fixed summation order: every rank gets the same bits.
+__global__ __launch_bounds__(64) void big_contract_kernel(const float *__restrict__ Z, CoreView A, int ncols, float *__restrict__ red) {
+  extern __shared__ __attribute__((aligned(16))) float sAc[];             // [(h, d)][h' padded to a multiple of 8]
+  const int hp = A.n_in, h = A.n_out, nI = hp * kD, HS = (h + 7) & ~7;
+  const int o0 = blockIdx.y * 8;
+  for (int e = threadIdx.x; e < nI * 8; e += 64) {                        // the eight columns of the core this workgroup uses
+    const int i = e >> 3, o = o0 + (e & 7);
+    sAc[e] = o < h ? A.base[(size_t)(i >> 1) * A.s_in + (i & 1) * A.s_d + (size_t)o * A.s_out] : 0.f;
+  }
+  (void)HS;
+  __syncthreads();
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c < ncols) {
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+    for (int i = 0; i < nI; ++i) {
+      const float z = Z[(size_t)i * ncols + c];
+      const float4 a = *reinterpret_cast<const float4 *>(sAc + 8 * i), b2 = *reinterpret_cast<const float4 *>(sAc + 8 * i + 4);
+      lo.x = fmaf(a.x, z, lo.x); lo.y = fmaf(a.y, z, lo.y); lo.z = fmaf(a.z, z, lo.z); lo.w = fmaf(a.w, z, lo.w);
+      hi.x = fmaf(b2.x, z, hi.x); hi.y = fmaf(b2.y, z, hi.y); hi.z = fmaf(b2.z, z, hi.z); hi.w = fmaf(b2.w, z, hi.w);
+    }
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (o0 + u < h) red[(size_t)(o0 + u) * ncols + c] = v[u];
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kMetricSlots)
+    red[(size_t)h * ncols + threadIdx.x] = Z[(size_t)nI * ncols + threadIdx.x];
+}
+
+bool launch_big_ext(const float *Eprev, const float *x_km1, const float *x_k, const CoreView &A, int b_pad, float *Ecur, float *Pk,
+                    hipStream_t st) {
+  const size_t lds = (size_t)A.n_in * kD * ((A.n_out + 3) & ~3) * sizeof(float);
+  if (A.n_out < 1 || lds > 160 * 1024 || b_pad % 64) {
+    snprintf(g_big_err, sizeof g_big_err, "big_ext_kernel: core %d x %d x %d, b_pad %d", A.n_in, kD, A.n_out, b_pad);
+    return false;
+  }
+  hipLaunchKernelGGL(big_ext_kernel, dim3(b_pad / 64, (A.n_out + 15) / 16), dim3(256), lds, st, Eprev, x_km1, x_k, A, b_pad, Ecur, Pk);
+  return true;
+}
+bool launch_big_contract(const float *Zred, const CoreView &A, int ncols, float *red, hipStream_t st) {
+  const size_t lds = (size_t)A.n_in * kD * 8 * sizeof(float);
+  if (A.n_out < 1 || lds > 160 * 1024 || ncols < 1) {
+    snprintf(g_big_err, sizeof g_big_err, "big_contract_kernel: core %d x %d x %d, %d columns", A.n_in, kD, A.n_out, ncols);
+    return false;
+  }
+  hipLaunchKernelGGL(big_contract_kernel, dim3((ncols + 63) / 64, (A.n_out + 7) / 8), dim3(64), lds, st, Zred, A, ncols, red);
+  return true;
+}
+
 // The part of the chain that needs neither the batch-summed gradient nor anything else the batch kernel of this step
 // produces: the merged tensor and T = Nh^T . B.  The host may enqueue it on a second stream beside the batch kernel
 // (`prep_only`), and then asks the chain proper to skip it (`skip_prep`).
-bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check, bool prep_only, bool skip_prep) {
+bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check, bool prep_only, bool skip_prep,
+                       hipEvent_t after_update) {
   const int D = kD, Bs = p.bsize;
   const int r = D * p.h, c = D * p.g * p.L;
   const bool short_rows = r <= c;
@@ -610,6 +762,11 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   if (prep_only) return true;
   BIG(big_wd_kernel, dim3(nb), dim3(kBT), 0, p, Bf, (const double *)s.T, ws, s.part);
   BIG(big_update_kernel, dim3(nb), dim3(kBT), 0, p, ws, (const double *)s.part, nb);
+  // B_new is complete: the batch kernel of the NEXT step may start beside the SVD of this one (pipelined large-tensor step)
+  if (after_update && hipEventRecord(after_update, st) != hipSuccess) {
+    snprintf(g_big_err, sizeof g_big_err, "hipEventRecord behind big_update_kernel failed");
+    return false;
+  }
   if (p.stop_after_update) return true;
   const int nt = (n + 15) / 16;
   BIG(big_gram_kernel, dim3(nt, nt, kGramKS), dim3(256), 0, (const float *)p.Bnew, n, len, si, sx, s.gram);

@@ -873,7 +873,9 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_kernel(WideParams
 //   * the staging buffers of the first phase (environments, extension core) aliased with the chunk buffer.
 // ------------------------------------------------------------------------------------------
 struct WideTiledSmem { float *sX, *sF, *sGl, *sPp, *sQp, *sH, *sP, *sQ, *U, *rH, *rGp, *rG, *rA, *sA, *sBc; size_t floats; };
-__host__ __device__ inline WideTiledSmem wide_tiled_carve(float *base, WideMfmaDims &d, int L, int h, int hp, int gp, int g) {
+// (ext = false: a launch that extends no environment -- the pipelined large-tensor step, whose row operand has D h rows -- needs no room
+//  for the extension core)
+__host__ __device__ inline WideTiledSmem wide_tiled_carve(float *base, WideMfmaDims &d, int L, int h, int hp, int gp, int g, bool ext = true) {
   WideTiledSmem w;
   d.RS = (d.JP * L) | 1;
   float *q = base;
@@ -891,8 +893,8 @@ __host__ __device__ inline WideTiledSmem wide_tiled_carve(float *base, WideMfmaD
   w.rH = a; a += up(hp, RPI) * kTS;
   w.rGp = a; a += up(gp, RPI) * kTS;
   w.rG = a; a += up(g, RPI) * kTS;
-  w.rA = a; a += up(hp * kD * h, 64);
-  w.sA = a; a += d.KA * d.HS;
+  w.rA = a; a += ext ? up(hp * kD * h, 64) : 0;
+  w.sA = a; a += ext ? d.KA * d.HS : 0;
   const size_t ua = (size_t)(a - q), ub = (size_t)16 * d.RS + 64;
   w.sBc = q;
   q += ua > ub ? ua : ub;
@@ -903,7 +905,7 @@ __host__ __device__ inline WideTiledSmem wide_tiled_carve(float *base, WideMfmaD
 __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(WideParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   WideMfmaDims dm = wide_mfma_dims(p.hp, p.gp, p.h, p.g);
-  const WideTiledSmem w = wide_tiled_carve(smem, dm, p.L, p.h, p.hp, p.gp, p.g);
+  const WideTiledSmem w = wide_tiled_carve(smem, dm, p.L, p.h, p.hp, p.gp, p.g, p.do_ext != 0 || p.Hcur == nullptr);
   const int tid = threadIdx.x, NT = kMfmaThreads;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -1114,6 +1116,16 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(Wide
     }
   }
 #undef GLDS
+}
+
+size_t wide_tiled_lds_bytes(int L, int h, int hp, int gp, int g, bool ext) {
+  alignas(16) static float origin[4];
+  WideMfmaDims dt = wide_mfma_dims(hp, gp, h, g);
+  if (L * (kTS / 16) > 4 * (kMfmaThreads / 64)) return 0;
+  return wide_tiled_carve(origin, dt, L, h, hp, gp, g, ext).floats * sizeof(float);
+}
+void launch_wide_tiled(const WideParams &p, int nblk, size_t lds_bytes, hipStream_t st) {
+  hipLaunchKernelGGL(wide_step_mfma_tiled_kernel, dim3(nblk), dim3(kMfmaThreads), lds_bytes, st, p);
 }
 
 // false: the operands of a sample tile fit neither MFMA kernel's LDS budget (bond dimensions beyond what this build handles)

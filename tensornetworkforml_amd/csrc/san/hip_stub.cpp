@@ -237,6 +237,24 @@ hipError_t hipLaunchKernel(const void *fn, dim3 g, dim3 b, void **args, size_t s
     need(*(const float **)args[0], (size_t)n * len * 4, "large-tensor path: B_new");
     need(*(double **)args[5], (size_t)8 * kBigMaxN * kBigMaxN * 8, "large-tensor path: partial Gram matrices");
     if (n > kBigMaxN || (n & 1)) die("big_gram_kernel: short side %d", n);
+  } else if (has("big_ext_kernel")) {      // (E_{k-1}, x_{k-1}, x_k, core view, b_pad, E_k, P'_k)
+    const CoreView &A = *(const CoreView *)args[3];
+    const size_t bp = *(int *)args[4];
+    if (g.x * 64 != bp) die("big_ext_kernel: grid %u x 64 samples != b_pad %zu", g.x, bp);
+    need(*(const float **)args[0], (size_t)A.n_in * bp * 4, "big_ext: E_{k-1}");
+    need(*(const float **)args[1], bp * kD * 4, "big_ext: x_{k-1}"); need(*(const float **)args[2], bp * kD * 4, "big_ext: x_k");
+    need(A.base, view_extent(A, 1) * 4, "big_ext: core");
+    need(*(float **)args[5], (size_t)A.n_out * bp * 4, "big_ext: E_k"); need(*(float **)args[6], (size_t)kD * A.n_out * bp * 4, "big_ext: P'_k");
+    if (shm < (size_t)A.n_in * kD * ((A.n_out + 3) & ~3) * 4) die("big_ext_kernel: %zu bytes of LDS for a %d x %d x %d core", shm, A.n_in, kD, A.n_out);
+    if ((int)g.y * 16 < A.n_out) die("big_ext_kernel: %u workgroup rows of 16 for %d bond indices", g.y, A.n_out);
+  } else if (has("big_contract_kernel")) { // (Z, core view, ncols, red)
+    const CoreView &A = *(const CoreView *)args[1];
+    const size_t nc = *(int *)args[2];
+    need(*(const float **)args[0], ((size_t)A.n_in * kD * nc + kMetricSlots) * 4, "big_contract: Z");
+    need(A.base, view_extent(A, 1) * 4, "big_contract: core");
+    need(*(float **)args[3], ((size_t)A.n_out * nc + kMetricSlots) * 4, "big_contract: raw gradient");
+    if (shm < (size_t)A.n_in * kD * 8 * 4) die("big_contract_kernel: %zu bytes of LDS", shm);
+    if ((size_t)g.x * 64 < nc || (int)g.y * 8 < A.n_out) die("big_contract_kernel: grid (%u, %u) for %zu columns, %d rows", g.x, g.y, nc, A.n_out);
   } else if (has("reduce_slabs")) {        // (slabs, nblk, slab_stride, n, red)
     const int nblk = *(int *)args[1], stride = *(int *)args[2], n = *(int *)args[3];
     if (n > stride) die("reduce_slabs: %d elements of a slab of %d", n, stride);

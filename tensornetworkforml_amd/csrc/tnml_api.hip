@@ -59,6 +59,15 @@ struct tnml_ctx {
   int split_upd = 0, split_bat = 0;          // index of the event recorded last
   bool split_pending = false;                // stream2 holds batch-side work `stream` has not waited for yet
   bool split_enabled = true;                 // tnml_set_comm_overlap
+  // pipelined large-tensor step (kernels_big.hip): the batch kernel of step k+1 runs on stream2 beside the SVD of step k and leaves
+  // the reduced pre-gradient Z_{k+1} in zred; the step then starts with the contraction A_k^T . Z instead of the batch kernel
+  bool bigpipe_enabled = true;               // tnml_set_step_pipeline(ctx, 0) turns it off together with the in-LDS pipeline
+  bool Zbig_valid = false;
+  int Zbig_k = -1, Zbig_left = 0, Zbig_act = 0, Zbig_loss = 0, Zbig_rows = 0, Zbig_cols = 0;
+  float Zbig_T = 0.f;
+  float *bigPk = nullptr;                    // [D * Mmax][b_pad]  E_k (x) x_k, the row operand of Z_{k+1}
+  hipEvent_t ev_upd_big = nullptr, ev_zbig = nullptr;
+  bool zbig_pending = false;                 // stream2 holds batch work of the pipelined large-tensor step the context's stream has not joined
   hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
   // host bookkeeping
   std::vector<int> bond;
@@ -192,7 +201,7 @@ static int alloc_batch_buffers(tnml_ctx *c, int b_cap) {
     c->pipe_ngroups = (c->pipe_nwide + kPipeGroupMax - 1) / kPipeGroupMax;
     HIP_TRY(hipMalloc(&c->zslabs, (size_t)c->pipe_nwide * c->zstride * sizeof(float)));
   }
-  c->Z_valid = false;
+  c->Z_valid = false; c->Zbig_valid = false;
   HIP_TRY(hipMemsetAsync(c->y, 0, (size_t)b_pad * sizeof(int), c->stream));
   HIP_TRY(hipMemsetAsync(c->f, 0, (size_t)c->L * b_pad * sizeof(float), c->stream));
   c->have_input = c->have_labels = false;
@@ -232,6 +241,8 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   HIP_TRY(hipEventCreateWithFlags(&c->ev_p3, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_upd_big, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_zbig, hipEventDisableTiming));
   for (int i = 0; i < 2; ++i) {
     HIP_TRY(hipEventCreateWithFlags(&c->ev_upd[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_bat[i], hipEventDisableTiming));
@@ -316,6 +327,9 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->ev_main) (void)hipEventDestroy(c->ev_main);
   if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
   for (int i = 0; i < 2; ++i) { if (c->ev_upd[i]) (void)hipEventDestroy(c->ev_upd[i]); if (c->ev_bat[i]) (void)hipEventDestroy(c->ev_bat[i]); }
+  if (c->ev_upd_big) (void)hipEventDestroy(c->ev_upd_big);
+  if (c->ev_zbig) (void)hipEventDestroy(c->ev_zbig);
+  if (c->bigPk) (void)hipFree(c->bigPk);
   if (c->ev_p0) (void)hipEventDestroy(c->ev_p0);
   if (c->ev_p2) (void)hipEventDestroy(c->ev_p2);
   if (c->ev_p3) (void)hipEventDestroy(c->ev_p3);
@@ -335,7 +349,7 @@ static int check_status(tnml_ctx *c) {
   if (st & 12) {
     HIP_TRY(hipMemset(c->sync, 0, sizeof(unsigned)));          // a late helper may have left the arrival counter mid-count
     HIP_TRY(hipMemset(c->pipe_cnt, 0, 17 * sizeof(unsigned)));
-    c->Z_valid = false;
+    c->Z_valid = false; c->Zbig_valid = false;
     return fail(TNML_ERR_STATE, "internal: a workgroup of a sweep-step launch never saw its hand-off (status %d)", st);
   }
   if (st & 1) return fail(TNML_ERR_NONFINITE, "non-finite values reached the bond update / SVD (status %d)", st);
@@ -419,7 +433,7 @@ extern "C" int tnml_set_cores(tnml_ctx *c, const float *flat, size_t n_floats, c
   c->Ln_valid = c->Rn_valid = false;
   c->f_current = false;
   c->Bnew_valid = false;
-  c->Z_valid = false;
+  c->Z_valid = false; c->Zbig_valid = false;
   return TNML_OK;
 }
 
@@ -465,7 +479,7 @@ extern "C" int tnml_scale_cores(tnml_ctx *c, double factor) {
   c->Ln_valid = c->Rn_valid = false;
   c->f_current = false;
   c->Bnew_valid = false;
-  c->Z_valid = false;
+  c->Z_valid = false; c->Zbig_valid = false;
   return TNML_OK;
 }
 
@@ -500,7 +514,7 @@ extern "C" int tnml_set_input(tnml_ctx *c, const float *X, const int32_t *y, int
   c->envs_valid_L = c->envs_valid_R = false;
   c->f_current = false;
   c->Bnew_valid = false;
-  c->Z_valid = false;
+  c->Z_valid = false; c->Zbig_valid = false;
   return TNML_OK;
 }
 
@@ -542,7 +556,7 @@ extern "C" int tnml_select_batch(tnml_ctx *c, int slot) {
   c->envs_valid_L = c->envs_valid_R = false;
   c->f_current = false;
   c->Bnew_valid = false;
-  c->Z_valid = false;
+  c->Z_valid = false; c->Zbig_valid = false;
   return TNML_OK;
 }
 
@@ -557,7 +571,7 @@ extern "C" int tnml_set_labels(tnml_ctx *c, const int32_t *y, int b) {
   HIP_TRY(hipMemcpyAsync(c->y, y, (size_t)b * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_labels = true;
-  c->Z_valid = false;             // the pre-gradient carries the loss derivative of the old labels
+  c->Z_valid = false; c->Zbig_valid = false;             // the pre-gradient carries the loss derivative of the old labels
   return TNML_OK;
 }
 
@@ -630,7 +644,7 @@ static int run_chain(tnml_ctx *c, bool logmode) {
     c->envs_valid_L = !right_envs;
     c->f_current = true;
     c->Bnew_valid = false;
-    c->Z_valid = false;
+    c->Z_valid = false; c->Zbig_valid = false;
   }
   return TNML_OK;
 }
@@ -721,7 +735,7 @@ extern "C" int tnml_set_f(tnml_ctx *c, const float *f) {
                            (size_t)c->b * sizeof(float), c->L, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->f_current = true;
-  c->Z_valid = false;             // a pre-gradient computed from the device's own f no longer applies
+  c->Z_valid = false; c->Zbig_valid = false;             // a pre-gradient computed from the device's own f no longer applies
   return TNML_OK;
 }
 
@@ -781,7 +795,7 @@ static int narrow_path(const tnml_ctx *c, int h, int g, int s, int L, int m) {
   return 1;
 }
 
-static int run_narrow(tnml_ctx *c, NarrowParams &n, int path, bool skip_prep = false) {
+static int run_narrow(tnml_ctx *c, NarrowParams &n, int path, bool skip_prep = false, hipEvent_t after_update = nullptr) {
   if (path == 0) {
     size_t lds = narrow_lds_bytes(n.h, n.g, n.s, n.L, n.m);
     if (n.fused && !n.prep_ready) lds = std::max(lds, prep_slice_lds_bytes(n.h, n.g, n.s, n.L));   // slice workgroups ride along
@@ -792,7 +806,7 @@ static int run_narrow(tnml_ctx *c, NarrowParams &n, int path, bool skip_prep = f
   int rc = ensure_big(c);
   if (rc) return rc;
   n.dbg = c->dbg;                       // the capture block is this path's workspace
-  if (!launch_narrow_big(n, c->big, c->stream, c->check_launches, false, skip_prep)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
+  if (!launch_narrow_big(n, c->big, c->stream, c->check_launches, false, skip_prep, after_update)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
   return TNML_OK;
 }
 
@@ -889,6 +903,10 @@ static bool wide_pipe_fits(const tnml_ctx *c, const WidePipeParams &w) {
 // Communicator path: whatever the batch-side stream still holds (f, environments, the exchanged pre-gradient) has to be complete
 // before the context's stream touches it outside a split step.
 static int split_join(tnml_ctx *c) {
+  if (c->zbig_pending) {
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_zbig, 0));
+    c->zbig_pending = false;
+  }
   if (c->split_pending) {
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_bat[c->split_bat], 0));
     c->split_pending = false;
@@ -1092,7 +1110,7 @@ static int sweep_persist(tnml_ctx *c, int left_dir, int n_steps, float lr, float
   c->prev_left_dir = left_dir;
   c->cnt_steps += n_steps; c->cnt_bytes += bytes; c->cnt_flops += flops;
   c->sweep_launches += 1; c->step_launches += n_steps; c->persist_sweeps += 1;
-  c->Bnew_valid = true; c->f_current = true; c->Z_valid = false;
+  c->Bnew_valid = true; c->f_current = true; c->Z_valid = false; c->Zbig_valid = false;
   return 1;
 }
 
@@ -1174,6 +1192,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       return fail(TNML_ERR_ARG, "new cores at sites (%d,%d) exceed the buffers sized for M = %d", p, p + 1, c->Mmax);
     const int npath = narrow_path(c, h, g, s, L, m);
     if (npath < 0) return npath;
+    bool f_by_z = false;          // f of this step stored by the batch kernel of the next one (pipelined large-tensor step)
 
     // ---- parameters of the narrow kernel (built first: the wide launch carries its slice workgroups) ---------
     // single GPU + in-LDS path: the slab reduction rides in the narrow launch as helper workgroups (no separate
@@ -1312,6 +1331,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       HIP_TRY(hipEventRecord(c->ev_bat[c->split_bat], c->stream2));
       c->split_pending = true;
       c->sweep_launches += 2; c->step_launches++;
+      c->Zbig_valid = false;
       c->Z_valid = wp.do_z != 0; c->Z_k = k + 1; c->Z_left = left_dir; c->Z_act = act_fn; c->Z_loss = loss_fn; c->Z_T = T;
     } else if (pipe) {
       if (need_prologue) {
@@ -1343,10 +1363,17 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       prof_end(c, 3);
       c->sweep_launches++; c->step_launches++;
       if (c->comm && wp.do_z) NCCL_TRY(ncclAllReduce(c->zred, c->zred, wp.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
+      c->Zbig_valid = false;
       c->Z_valid = wp.do_z != 0; c->Z_k = k + 1; c->Z_left = left_dir; c->Z_act = act_fn; c->Z_loss = loss_fn; c->Z_T = T;
     } else {
+      // pipelined large-tensor step: is the reduced pre-gradient of THIS step waiting in zred (left there by the batch kernel that
+      // ran on stream2 beside the previous step's SVD)?
+      bool zbig = false;
+      if (c->Zbig_valid && k >= 3 && c->Zbig_k == k && c->Zbig_left == left_dir && c->Zbig_act == act_fn && c->Zbig_loss == loss_fn && c->Zbig_T == T &&
+          npath == 1 && mode == 0 && !Bdirect_dev)
+        zbig = c->Zbig_cols == D * D * g * L && c->Zbig_rows == D * (left_dir ? c->mr(p + 2) : c->ml(p - 1));
       { int rc = split_join(c); if (rc) return rc; }
-      c->Z_valid = false;
+      c->Z_valid = false; c->Zbig_valid = false;
       // ---- wide kernel -----------------------------------------------------------------------
       WideParams w{};
       w.b = c->b; w.b_pad = c->b_pad; w.L = L;
@@ -1391,8 +1418,10 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       // Large-tensor step: the merged tensor and T = Nh^T . B need nothing this step's batch kernel produces -- they run on
       // a second stream beside it (two of the chain's fourteen launches, 30 us of a 380 us C5 step), joined by an event
       // before the weight-decay kernel reads them.
+      // (a step that takes its gradient from Z has no batch kernel to hide them behind: they stay on the context's stream, in front of
+      // the chain, and the two cross-queue hops -- 10 us each -- are saved)
       bool prep_ahead = false;
-      if (npath == 1 && mode == 0 && !Bdirect_dev) {
+      if (npath == 1 && mode == 0 && !Bdirect_dev && !zbig) {
         { int rc = ensure_big(c); if (rc) return rc; }
         HIP_TRY(hipEventRecord(c->ev_main, c->stream));                  // everything the previous step wrote
         HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_main, 0));
@@ -1402,7 +1431,10 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       }
       prof_begin(c);
       bool prep_done = false;
-      if (!launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream, &prep_done))
+      if (zbig) {
+        // raw gradient = A_{k-1}^T . Z_k (+ the metric tail): no batch kernel, no slab reduction, no exchange on this stream
+        if (!launch_big_contract(c->zred, w.ext_core, D * D * g * L, c->red, c->stream)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
+      } else if (!launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream, &prep_done))
         return fail(TNML_ERR_ARG, "step at sites (%d,%d): a 32-sample tile of this bond dimension does not fit the batch kernels' LDS", p, p + 1);
       n.prep_ready = prep_done ? 1 : 0;
       // slices the batch launch could not host would ride in the update launch -- unless they do not fit a workgroup's LDS
@@ -1413,17 +1445,69 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       if (n.fused) n.wait_count = n.nred + (n.prep_ready ? 0 : kD * kD);
       prof_end(c, 1);
       // ---- reduce (+ all-reduce over the batch shards) -----------------------------------------
-      if (!fused_now) {
+      if (!fused_now && !zbig) {
         prof_begin(c);
         launch_reduce(c->slabs, nblk, c->slab_stride, (int)bsize + kMetricSlots, c->red, c->stream);
         prof_end(c, 2);
       }
-      if (c->comm) NCCL_TRY(ncclAllReduce(c->red, c->red, bsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
+      if (c->comm && !zbig) NCCL_TRY(ncclAllReduce(c->red, c->red, bsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream));
       prof_begin(c);
       if (prep_ahead) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_prep, 0));
-      { int rc = run_narrow(c, n, npath, prep_ahead); if (rc) return rc; }
+      // ---- pipelined large-tensor step: may the batch kernel of step k+1 run beside the SVD of this one? ----------------------
+      // Needs: the next step is a large-tensor step too, both environments exist as arrays (k >= 2, an ahead environment two sites
+      // on), the tiled batch kernel takes the doubled row operand (h -> D h), the slabs of Z fit the pre-gradient scratch.
+      bool next_z = false;
+      int gnext = 0;
+      size_t lds_z = 0;
+      if (c->bigpipe_enabled && c->pipe_enabled && npath == 1 && mode == 0 && !Bdirect_dev && !c->debug && !c->profile && trunc_policy != TNML_TRUNC_ADAPTIVE &&
+          k >= 2 && k + 1 <= N - 2 && nblk <= c->pipe_nwide) {
+        const int pn = left_dir ? p - 1 : p + 1;                   // sites (pn, pn + 1) of step k+1
+        gnext = left_dir ? c->ml(pn) : c->mr(pn + 1);
+        const int snext = left_dir ? c->ml(p) : c->mr(p + 1);      // == g: the bond the two steps share
+        const int mnext = tnml_trunc_rank(trunc_policy, left_dir, pn, N, left_dir ? c->ml(pn) : m, D, left_dir ? m : c->mr(pn + 1), L, c->Mpol);
+        const size_t zs = (size_t)D * h * D * D * gnext * L;
+        lds_z = wide_tiled_lds_bytes(L, D * h, h, g, gnext, false);      // (its launch extends no environment and hands Hcur in)
+        next_z = mnext > 0 && narrow_path(c, m, gnext, snext, L, mnext) == 1 && zs + kMetricSlots <= (size_t)c->zstride &&
+                 lds_z > 0 && lds_z <= 160 * 1024 && D * h <= 2 * c->Mmax && (size_t)D * h * c->b_pad <= (size_t)2 * c->Mmax * c->b_pad;
+      }
+      if (next_z && !c->bigPk) HIP_TRY(hipMalloc(&c->bigPk, (size_t)D * c->Mmax * c->b_pad * sizeof(float)));
+      { int rc = run_narrow(c, n, npath, prep_ahead, next_z ? c->ev_upd_big : nullptr); if (rc) return rc; }
       prof_end(c, 3);
-      c->sweep_launches += (fused_now ? 2 : 3) + (npath == 1 ? 11 : 0);
+      if (zbig && !next_z) {
+        // a step that took its gradient from Z launched no batch kernel, and none for the next step either: the behind environment
+        // E_k the next (classic) step extends has to be formed here
+        if (!launch_big_ext(w.Hprev, w.x_km1, w.x_k, w.ext_core, c->b_pad, w.Hcur, c->bigPk, c->stream)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
+        c->sweep_launches += 1;
+      }
+      if (next_z) {
+        // stream2, behind B_new(k): E_k and P'_k = E_k (x) x_k; then the tiled batch kernel "of step k+1" with P'_k in the place of its
+        // behind environment (D h rows): f of step k from B_new(k) and the slabs of Z_{k+1}; their sum; the exchange.
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upd_big, 0));
+        if (!launch_big_ext(w.Hprev, w.x_km1, w.x_k, w.ext_core, c->b_pad, w.Hcur, c->bigPk, c->stream2)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
+        WideParams z{};
+        z.b = c->b; z.b_pad = c->b_pad; z.L = L;
+        z.h = D * h; z.g = gnext; z.hp = h; z.gp = g;
+        z.do_f = 1; z.do_ext = 0; z.first_ext = 0;
+        z.act_fn = act_fn; z.loss_fn = loss_fn; z.T = T;
+        z.x_km1 = w.x_k; z.x_k = w.x_kp1;
+        z.x_kp1 = c->X + (size_t)(left_dir ? p - 1 : p + 2) * c->b_pad * D;
+        z.Hprev = w.Hcur; z.Hcur = c->bigPk;
+        z.Gprev = w.Gcur;
+        { const int gs2 = left_dir ? p - 2 : p + 3; z.Gcur = (gs2 >= 0 && gs2 <= N - 1) ? c->env_slot(ahe, gs2) : nullptr; }
+        z.Bprev = c->Bnew;
+        z.y = c->y; z.f = c->f;
+        z.slabs = c->zslabs; z.slab_stride = c->zstride; z.bsize = (int)((size_t)D * h * D * D * gnext * L);
+        launch_wide_tiled(z, nblk, lds_z, c->stream2);
+        launch_reduce(c->zslabs, nblk, c->zstride, z.bsize + kMetricSlots, c->zred, c->stream2);
+        if (c->comm) NCCL_TRY(ncclAllReduce(c->zred, c->zred, z.bsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream2));
+        HIP_TRY(hipEventRecord(c->ev_zbig, c->stream2));
+        c->zbig_pending = true;
+        c->Zbig_valid = true; c->Zbig_k = k + 1; c->Zbig_left = left_dir; c->Zbig_act = act_fn; c->Zbig_loss = loss_fn; c->Zbig_T = T;
+        c->Zbig_rows = D * h; c->Zbig_cols = D * D * gnext * L;
+        c->sweep_launches += 3;
+        f_by_z = true;
+      }
+      c->sweep_launches += (zbig ? 1 : (fused_now ? 2 : 3)) + (npath == 1 ? 11 : 0);
       c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
       if (mode == 1) {
         // the behind environment list grew (as update_B does, Network_class.py:637-652); nothing else changes
@@ -1454,7 +1538,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       c->cnt_flops += 4.0 * bb * D * D * h * g * L + 2.0 * bb * D * h * h;
     }
     c->Bnew_valid = true;
-    c->f_current = pipe;          // the batch-side workgroups of a pipelined launch stored f of this step already
+    c->f_current = pipe || f_by_z;          // the batch-side work of a pipelined step stored f of this step already
     c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
     if (c->check_launches) HIP_TRY(hipGetLastError());
     if (c->sync_interval > 0 && (step + 1) % c->sync_interval == 0) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1704,8 +1788,9 @@ extern "C" int tnml_set_chain_path(tnml_ctx *c, int force_plain) {
 extern "C" int tnml_set_step_pipeline(tnml_ctx *c, int on) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   c->pipe_enabled = on != 0;
+  c->bigpipe_enabled = on != 0;
   c->pipe_tiles = on >= 2 ? on : (on == 1 ? 2 : 1);
-  c->Z_valid = false;
+  c->Z_valid = false; c->Zbig_valid = false;
   return TNML_OK;
 }
 

@@ -188,7 +188,14 @@ constexpr int kBigParts = 512;
 size_t big_jacobi_lds_bytes(int n);
 // false: a launch of the path was illegal or (check) failed; big_launch_error() names it
 bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check, bool prep_only = false,
-                       bool skip_prep = false);
+                       bool skip_prep = false, hipEvent_t after_update = nullptr);
+// pipelined large-tensor step: behind environment + (h, d) operand of the pre-gradient; raw gradient = A^T . Z (kernels_big.hip)
+bool launch_big_ext(const float *Eprev, const float *x_km1, const float *x_k, const CoreView &A, int b_pad, float *Ecur, float *Pk,
+                    hipStream_t st);
+bool launch_big_contract(const float *Zred, const CoreView &A, int ncols, float *red, hipStream_t st);
+// LDS the tiled batch kernel asks for at these dimensions (0: the shape is beyond it)
+size_t wide_tiled_lds_bytes(int L, int h, int hp, int gp, int g, bool ext);
+void launch_wide_tiled(const WideParams &p, int nblk, size_t lds_bytes, hipStream_t st);
 const char *big_launch_error();
 size_t narrow_lds_bytes(int h, int g, int s, int L, int m);
 void launch_norm_chain(const NormChainSite *sites_dev, int n_sites, const float *cores, double *env_base,
