@@ -68,7 +68,13 @@ static void run(const Cfg &c, int mode) {
   std::vector<float> f((size_t)c.L * c.b), met((size_t)2 * (c.N - 1));
   double lm = 0;
   OK(tnml_forward_logabsmax(ctx, &lm));
+  // staged batches (the bench's data path): two slots, one of them ragged, selected in turn
+  OK(tnml_stage_batch(ctx, 0, X.data(), y.data(), c.b));
+  OK(tnml_stage_batch(ctx, 1, X.data(), y.data(), c.b > 3 ? c.b - 3 : c.b));
+  OK(tnml_stage_batch(ctx, 1, X.data(), y.data(), c.b));            // re-staging a slot replaces it
+  if (tnml_select_batch(ctx, 5) == TNML_OK) { fprintf(stderr, "selecting an empty slot succeeded\n"); exit(1); }
   for (int sw = 0; sw < c.sweeps; ++sw) {
+    OK(tnml_select_batch(ctx, sw & 1));
     OK(tnml_forward(ctx, f.data()));
     const int left = tnml_l_pos(ctx) == c.N - 1;
     // a sweep in two calls (the second continues mid-chain), as Network.sweep may be driven

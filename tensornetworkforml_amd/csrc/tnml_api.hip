@@ -526,18 +526,32 @@ extern "C" int tnml_stage_batch(tnml_ctx *c, int slot, const float *X, const int
     if (y[i] < 0 || y[i] >= c->L) return fail(TNML_ERR_ARG, "label %d of sample %d outside [0, %d)", y[i], i, c->L);
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (c->stageX[slot]) { (void)hipFree(c->stageX[slot]); (void)hipFree(c->stageY[slot]); c->stageX[slot] = nullptr; c->stageY[slot] = nullptr; }
-  HIP_TRY(hipMalloc(&c->stageX[slot], (size_t)b * c->N * c->D * sizeof(float)));
-  HIP_TRY(hipMalloc(&c->stageY[slot], (size_t)b * sizeof(int)));
-  HIP_TRY(hipMemcpy(c->stageX[slot], X, (size_t)b * c->N * c->D * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->stageY[slot], y, (size_t)b * sizeof(int), hipMemcpyHostToDevice));
-  c->stageB[slot] = b;
+  // the slot is either complete (both arrays, its size) or empty: any failure below leaves it empty
+  auto drop = [&]() {
+    if (c->stageX[slot]) (void)hipFree(c->stageX[slot]);
+    if (c->stageY[slot]) (void)hipFree(c->stageY[slot]);
+    c->stageX[slot] = nullptr; c->stageY[slot] = nullptr; c->stageB[slot] = 0;
+  };
+  drop();
+  float *sx = nullptr;
+  int *sy = nullptr;
+  hipError_t e = hipMalloc(&sx, (size_t)b * c->N * c->D * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&sy, (size_t)b * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(sx, X, (size_t)b * c->N * c->D * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(sy, y, (size_t)b * sizeof(int), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (sx) (void)hipFree(sx);
+    if (sy) (void)hipFree(sy);
+    return fail(TNML_ERR_HIP, "staging a batch of %d samples failed: %s", b, hipGetErrorString(e));
+  }
+  c->stageX[slot] = sx; c->stageY[slot] = sy; c->stageB[slot] = b;
   return TNML_OK;
 }
 
 extern "C" int tnml_select_batch(tnml_ctx *c, int slot) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
-  if (slot < 0 || slot >= tnml_ctx::kStageSlots || !c->stageX[slot]) return fail(TNML_ERR_ARG, "slot %d holds no staged batch", slot);
+  if (slot < 0 || slot >= tnml_ctx::kStageSlots || !c->stageX[slot] || !c->stageY[slot] || c->stageB[slot] < 1)
+    return fail(TNML_ERR_ARG, "slot %d holds no staged batch", slot);
   HIP_TRY(hipSetDevice(c->device));
   const int b = c->stageB[slot];
   if (b > c->b_cap) {
