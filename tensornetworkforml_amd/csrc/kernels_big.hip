@@ -693,7 +693,19 @@ __global__ __launch_bounds__(64) void big_contract_kernel(const float *__restric
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c < ncols) {
     float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-    for (int i = 0; i < nI; ++i) {
+    int i = 0;
+    for (; i + 8 <= nI; i += 8) {                   // eight rows of Z in flight (one wave per workgroup: nothing else hides the latency)
+      float z[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z[u] = Z[(size_t)(i + u) * ncols + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 a = *reinterpret_cast<const float4 *>(sAc + 8 * (i + u)), b2 = *reinterpret_cast<const float4 *>(sAc + 8 * (i + u) + 4);
+        lo.x = fmaf(a.x, z[u], lo.x); lo.y = fmaf(a.y, z[u], lo.y); lo.z = fmaf(a.z, z[u], lo.z); lo.w = fmaf(a.w, z[u], lo.w);
+        hi.x = fmaf(b2.x, z[u], hi.x); hi.y = fmaf(b2.y, z[u], hi.y); hi.z = fmaf(b2.z, z[u], hi.z); hi.w = fmaf(b2.w, z[u], hi.w);
+      }
+    }
+    for (; i < nI; ++i) {
       const float z = Z[(size_t)i * ncols + c];
       const float4 a = *reinterpret_cast<const float4 *>(sAc + 8 * i), b2 = *reinterpret_cast<const float4 *>(sAc + 8 * i + 4);
       lo.x = fmaf(a.x, z, lo.x); lo.y = fmaf(a.y, z, lo.y); lo.z = fmaf(a.z, z, lo.z); lo.w = fmaf(a.w, z, lo.w);
