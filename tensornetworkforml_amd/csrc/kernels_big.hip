@@ -207,11 +207,102 @@ struct BigJacobiArgs {
   int *info;             // [0] rounds applied, [1] sweeps, [2] converged
   unsigned long long *counters;
   int *status;
+  // The replay of the rotation log rides in the same launch (round 3): workgroups 1.. apply the rotations to the unit vectors and to
+  // the columns of W WHILE workgroup 0 produces them, sixteen vectors per workgroup (one per wave).  Hand-off: the log is written
+  // with 16-byte agent-scope stores; once the entries of round r are known to be in memory (they were stored a whole round
+  // earlier: `s_waitcnt vmcnt(1)` costs nothing) lane 0 publishes `token << 12 | rounds ready` in prog[0]; prog[1] gets the final
+  // round count the same way when the iteration has ended.  The token makes words of earlier launches read as "nothing yet".
+  const float *Bn;
+  int len, si, sx;
+  double *VW;
+  unsigned *prog;
+  unsigned token;
 };
+
+// A replay workgroup: sixteen vectors, one per wave (pair k on lane k, the tournament move by one-lane wave shifts, as the eigenvector
+// waves of the in-LDS kernel).  ONE thread of the workgroup polls the two progress words and hands what it saw to the others
+// through LDS: with every wave polling (1100 of them, the same cache line) the update workgroup's own stores to that line
+// queued behind the polls and the iteration crawled -- an intermittent time-out in the first build.
+__device__ inline void big_replay_block(const BigJacobiArgs &a, int *sPoll) {
+  const int n = a.n, np = n / 2, k = threadIdx.x & 63;
+  const int v = 16 * ((int)blockIdx.x - 1) + (int)(threadIdx.x >> 6);
+  const bool have = v < n + a.len;                       // (waves without a vector still meet the barriers)
+  const int kk = k < np ? k : np - 1;
+  double top = 0.0, bot = 0.0;
+  if (have) {
+    if (v < n) { top = (2 * kk == v) ? 1.0 : 0.0; bot = (2 * kk + 1 == v) ? 1.0 : 0.0; }
+    else {
+      const size_t x = (size_t)(v - n) * a.sx;
+      top = (double)a.Bn[(size_t)(2 * kk) * a.si + x];
+      bot = (double)a.Bn[(size_t)(2 * kk + 1) * a.si + x];
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rlog = sc1_rsrc(a.rotlog);
+  constexpr int CH = 8;
+  int done_r = 0;                      // rounds applied
+  while (true) {
+    if (threadIdx.x == 0) {
+      // how far may this workgroup go?  (bounded: a producer that never comes sets a status bit and the workgroup gives up)
+      int avail = 0, ended = 0;
+      for (int spin = 0; spin < (1 << 21); ++spin) {
+        const unsigned v1 = __hip_atomic_load(a.prog + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v1 >> 12) == a.token) { ended = 1; avail = (int)(v1 & 4095u); break; }
+        const unsigned v0 = __hip_atomic_load(a.prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        avail = (v0 >> 12) == a.token ? (int)(v0 & 4095u) : 0;
+        if (avail >= done_r + CH) break;
+        __builtin_amdgcn_s_sleep(64);
+      }
+      if (!ended && avail < done_r + CH) {               // timed out: leave what was seen for the host's message
+        if (atomicOr(a.status, 16) == 0) {
+          a.prog[2] = a.token; a.prog[3] = __hip_atomic_load(a.prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          a.prog[4] = __hip_atomic_load(a.prog + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a.prog[5] = (unsigned)done_r; a.prog[6] = (unsigned)v;
+        }
+        ended = 2;                                       // give up
+      }
+      sPoll[0] = avail; sPoll[1] = ended;
+    }
+    __syncthreads();
+    const int avail = sPoll[0], ended = sPoll[1];
+    __syncthreads();                                     // (the words are rewritten by the next poll)
+    if (ended == 2) return;
+    const int upto = ended ? avail : done_r + ((avail - done_r) / CH) * CH;
+    while (done_r < upto) {
+      double2 cs[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int rr = min(done_r + u, upto - 1);
+        const tn_uvec4 raw = ld_sc1_b128(rlog, (unsigned)(((size_t)rr * np + kk) * sizeof(double2)));
+        cs[u] = __builtin_bit_cast(double2, raw);
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        if (done_r + u >= upto) break;                  // block-uniform
+        const double nt = cs[u].x * top - cs[u].y * bot, nb = cs[u].y * top + cs[u].x * bot;
+        if (np > 1) {
+          const double t1 = dpp_f64<0x138>(nt), b1 = dpp_f64<0x138>(nb), c1 = dpp_f64<0x130>(nb);
+          top = k == 0 ? nt : (k == 1 ? b1 : t1);
+          bot = k == np - 1 ? nt : c1;
+        } else {
+          top = nt; bot = nb;
+        }
+      }
+      done_r = min(done_r + CH, upto);
+    }
+    if (ended) break;
+  }
+  if (have && k < np) {
+    a.VW[(size_t)v * n + 2 * k] = top;
+    a.VW[(size_t)v * n + 2 * k + 1] = bot;
+  }
+}
 
 __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, NT = 1024;
+  if (blockIdx.x > 0) {
+    big_replay_block(a, (int *)smem_raw);
+    return;
+  }
   const int n = a.n, m = a.m, np = n / 2, ne = n;
   const int nblk = np * (np + 1) / 2;
   double *G0 = (double *)smem_raw, *G1 = G0 + 4 * (size_t)nblk;
@@ -310,12 +401,13 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
     // dependent chain that sets the length of a round runs in float32, the threads that APPLY a rotation refine its cosine
     // to float64 themselves (rot_corr), and the log for the replay kernel gets the refined (c, s) off the critical path.
     const float kept_lo = 1e-36f;
+    const __amdgpu_buffer_rsrc_t rlog = sc1_rsrc(a.rotlog);
     auto publish = [&](double *o, const RotT &r, int applied, size_t log_at) {
       *reinterpret_cast<double2 *>(o) = make_double2((double)r.t, (double)r.c0);
       *reinterpret_cast<float2 *>(o + 2) = make_float2(r.t, r.c0);
       if (r.level >= 2) sFlag[2 + (applied & 1)] = applied + 1;
       const double c = (double)r.c0 * rot_corr((double)r.t, (double)r.c0);
-      a.rotlog[log_at] = make_double2(c, c * (double)r.t);
+      st_sc1_b128(rlog, (unsigned)(log_at * sizeof(double2)), __builtin_bit_cast(tn_uvec4, make_double2(c, c * (double)r.t)));
     };
     if (isParam) {
       const int sl = 4 * blk_index(tid, tid, np);
@@ -363,6 +455,12 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
           const float ng = rb ? fmaf(sB, h0, cB * h1) : fmaf(cB, h0, -sB * h1);
           const RotT r = jacobi_rot_f32(na, nb, ng, fmaxf((float)kept2, kept_lo), (float)abs2, (float)a.stop2);
           publish(dCS + ((cur ^ 1) * np + tid) * 4, r, rounds + 1, (size_t)(rounds + 1) * np + tid);
+        }
+        if (tid < 64) {
+          // wave 0 holds every parameter thread: all of its log stores but the one just issued are complete -> the entries of
+          // rounds 0 .. `rounds` are in memory (they were stored one round ago and earlier)
+          asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          if (tid == 0) __hip_atomic_store(a.prog, (a.token << 12) | (unsigned)(rounds + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // The items of a lane as INDEPENDENT chains: all operands are requested first, the (dependent, 40-cycle) float64 steps of the
         // items interleave, stores last.  A per-item `if (!valid) continue` made them run one after the other: a round of the
@@ -420,6 +518,13 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
   } else {
     converged = 1;
   }
+  if (tid < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every log entry is in memory
+    if (tid == 0) {
+      __hip_atomic_store(a.prog + 1, (a.token << 12) | (unsigned)rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.prog, (a.token << 12) | (unsigned)rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   for (int j = tid; j < n; j += NT) a.lam[j] = __builtin_amdgcn_ldexp(fmax(diag(Gc, j), 0.0), sc_exp);
   if (tid == 0) {
     a.info[0] = rounds; a.info[1] = sweeps; a.info[2] = converged;
@@ -429,55 +534,6 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
       atomicAdd(a.counters + 2, (unsigned long long)rounds);
     }
     if (!converged) atomicOr(a.status, 2);
-  }
-}
-
-// ---- replay of the rotation log: one wavefront per vector, pair k on lane k --------------------------------------
-//   vector v < n: unit vector e_v (-> row v of V);  v >= n: column x = v - n of W (-> row x of W^T V)
-__global__ __launch_bounds__(64) void big_replay_kernel(const float *__restrict__ Bn, int n, int len, int si, int sx,
-                                                       const double2 *__restrict__ rotlog, const int *__restrict__ info,
-                                                       double *__restrict__ VW) {
-  const int v = blockIdx.x, k = threadIdx.x, np = n / 2;
-  const int kk = k < np ? k : np - 1;
-  double top, bot;
-  if (v < n) { top = (2 * kk == v) ? 1.0 : 0.0; bot = (2 * kk + 1 == v) ? 1.0 : 0.0; }
-  else {
-    const size_t x = (size_t)(v - n) * sx;
-    top = (double)Bn[(size_t)(2 * kk) * si + x];
-    bot = (double)Bn[(size_t)(2 * kk + 1) * si + x];
-  }
-  const int T = info[0];
-  // the log is read eight rounds at a time, the next chunk in flight while this one is applied
-  constexpr int CH = 8;
-  double2 nxt[CH];
-#pragma unroll
-  for (int u = 0; u < CH; ++u) nxt[u] = u < T ? rotlog[(size_t)u * np + kk] : make_double2(1.0, 0.0);
-  for (int r0 = 0; r0 < T; r0 += CH) {
-    double2 curc[CH];
-#pragma unroll
-    for (int u = 0; u < CH; ++u) curc[u] = nxt[u];
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const int rr = r0 + CH + u;
-      nxt[u] = rr < T ? rotlog[(size_t)rr * np + kk] : make_double2(1.0, 0.0);
-    }
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      if (r0 + u >= T) break;                     // wave-uniform
-      const double2 cs = curc[u];
-      const double nt = cs.x * top - cs.y * bot, nb = cs.y * top + cs.x * bot;
-      if (np > 1) {
-        const double t1 = dpp_f64<0x138>(nt), b1 = dpp_f64<0x138>(nb), c1 = dpp_f64<0x130>(nb);
-        top = k == 0 ? nt : (k == 1 ? b1 : t1);
-        bot = k == np - 1 ? nt : c1;
-      } else {
-        top = nt; bot = nb;
-      }
-    }
-  }
-  if (k < np) {
-    VW[(size_t)v * n + 2 * k] = top;
-    VW[(size_t)v * n + 2 * k + 1] = bot;
   }
 }
 
@@ -785,9 +841,11 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   BigJacobiArgs a{};
   a.G = s.gram; a.n = n; a.m = p.m; a.stop2 = p.svd_stop2; a.rotlog = s.rotlog; a.lam = s.lam; a.info = s.info;
   a.counters = p.counters; a.status = p.status;
-  BIG(big_jacobi_kernel, dim3(1), dim3(1024), big_jacobi_lds_bytes(n), a);
-  BIG(big_replay_kernel, dim3(n + len), dim3(64), 0, (const float *)p.Bnew, n, len, si, sx, (const double2 *)s.rotlog,
-      (const int *)s.info, s.VW);
+  a.Bn = p.Bnew; a.len = len; a.si = si; a.sx = sx; a.VW = s.VW; a.prog = s.prog; a.token = p.token & 0xfffffu;
+  // workgroup 0 iterates; workgroups 1.. replay its rotation log on the n unit vectors and the len columns of W while it does
+  // (they need no LDS but share the launch's request: all of them resident beside the batch kernel of the next step, whose 157
+  // workgroups leave 99 CUs)
+  BIG(big_jacobi_kernel, dim3(1 + (n + len + 15) / 16), dim3(1024), big_jacobi_lds_bytes(n), a);
   BIG(big_order_kernel, dim3(1), dim3(128), 0, p, s.lam, s.info, ws);
   BIG(big_cores_kernel, dim3(std::min(((n + len) * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, p, (const double *)s.lam,
       (const int *)s.info, (const double *)s.VW, s.Cb);

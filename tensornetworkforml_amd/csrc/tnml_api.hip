@@ -310,7 +310,7 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->comm) ncclCommDestroy(c->comm);
   void *ptrs[] = {c->X, c->Xstage, c->y, c->f, c->ftmp, c->ftmp2, c->Lenv, c->Renv, c->cores, c->lab[0], c->lab[1],
                   c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2,
-                  c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->zslabs, c->gslabs, c->zred, c->pipe_cnt, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2};
+                  c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->zslabs, c->gslabs, c->zred, c->pipe_cnt, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2, c->big.prog};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   void *pptrs[] = {c->zred2, c->Tbuf[0], c->Tbuf[1], c->TNbuf[0], c->TNbuf[1], c->prepRaw, c->Apub, c->pst_dev, c->pst_cnt, c->pst_flags};
   for (void *p : pptrs) if (p) (void)hipFree(p);
@@ -346,10 +346,16 @@ static int check_status(tnml_ctx *c) {
   HIP_TRY(hipMemcpy(&st, c->status, sizeof(int), hipMemcpyDeviceToHost));
   if (!st) return TNML_OK;
   HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
-  if (st & 12) {
+  if (st & 28) {        // 4: helpers late, 8: B_new flag never seen, 16: the replay workgroups never saw the rotation log grow
     HIP_TRY(hipMemset(c->sync, 0, sizeof(unsigned)));          // a late helper may have left the arrival counter mid-count
     HIP_TRY(hipMemset(c->pipe_cnt, 0, 17 * sizeof(unsigned)));
     c->Z_valid = false; c->Zbig_valid = false;
+    if ((st & 16) && c->big_ready) {
+      unsigned pw[8] = {0};
+      (void)hipMemcpy(pw, c->big.prog, sizeof pw, hipMemcpyDeviceToHost);
+      return fail(TNML_ERR_STATE, "internal: a replay workgroup never saw the rotation log grow (status %d; its token %u, progress word %u:%u, final word %u:%u, "
+                  "rounds applied %u, vector %u; host token %u)", st, pw[2], pw[3] >> 12, pw[3] & 4095u, pw[4] >> 12, pw[4] & 4095u, pw[5], pw[6], c->token & 0xfffffu);
+    }
     return fail(TNML_ERR_STATE, "internal: a workgroup of a sweep-step launch never saw its hand-off (status %d)", st);
   }
   if (st & 1) return fail(TNML_ERR_NONFINITE, "non-finite values reached the bond update / SVD (status %d)", st);
@@ -793,6 +799,8 @@ static int ensure_big(tnml_ctx *c) {
   HIP_TRY(hipMalloc(&c->big.VW, rows_cols * kBigMaxN * sizeof(double)));
   HIP_TRY(hipMalloc(&c->big.Cb, rows_cols * c->Mmax * sizeof(float)));
   HIP_TRY(hipMalloc(&c->big.T2, rows_cols * c->Mmax * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->big.prog, 8 * sizeof(unsigned)));
+  HIP_TRY(hipMemset(c->big.prog, 0, 8 * sizeof(unsigned)));
   c->big_ready = true;
   return TNML_OK;
 }
@@ -820,6 +828,7 @@ static int run_narrow(tnml_ctx *c, NarrowParams &n, int path, bool skip_prep = f
   int rc = ensure_big(c);
   if (rc) return rc;
   n.dbg = c->dbg;                       // the capture block is this path's workspace
+  n.token = ++c->token;                 // (tags the progress words of the replay that rides in the Jacobi launch)
   if (!launch_narrow_big(n, c->big, c->stream, c->check_launches, false, skip_prep, after_update)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
   return TNML_OK;
 }

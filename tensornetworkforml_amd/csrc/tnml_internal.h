@@ -182,6 +182,7 @@ struct BigScratch {
   double *VW;         // [(rows + cols)][n]  V, then W^T V
   float *Cb;          // [rows][m]  new behind core, contiguous
   double *T2;         // [rows][m]
+  unsigned *prog;     // [2] progress / final word of the replay that rides in the Jacobi launch (kernels_big.hip)
 };
 constexpr int kBigMaxN = 128;
 constexpr int kBigParts = 512;
