@@ -175,7 +175,6 @@ __global__ __launch_bounds__(kChainThreads) void env_chain_kernel(
 //     layout through a 2 KB LDS tile (written and read by the same wave: in order, no barrier).
 // The plain-FMA kernel remains for bonds > 32 and for the renormalising calibration pass.
 // ------------------------------------------------------------------------------------------
-constexpr int kChainMaxKS = 16;         // k-steps of 4: n_in <= 32
 constexpr int kChainLD = 36;            // row stride of the wave's result tile (16-byte reads along a row of bond indices)
 constexpr int kChainCoreMax = 32 * kD * 32;
 constexpr int kChainBlock = 8;          // sites per feature request

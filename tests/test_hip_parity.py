@@ -341,6 +341,10 @@ def test_rccl_exchange_beside_the_svd(monkeypatch):
 
 # default threshold: worst product error observed between 2.6e-6 and 2.6e-5 over builds that differ only in the rounding
 # order of float64 sums (the worst step of two late sweeps is a tail statistic of a chaotic trajectory)
+# (median, 90th percentile) bounds at <= 10 x the observed 9.9e-8 / 2.0e-6 (default), 1.8e-6 / 3.3e-5 (1e-4), 6.9e-8 / 1.1e-7 (1e-8)
+MED_TOL = {None: (1e-6, 2e-5), 1e-4: (1.8e-5, 3.3e-4), 1e-8: (7e-7, 1.1e-6)}
+
+
 @pytest.mark.parametrize('stop2,tol', [(None, 5e-5), (1e-4, 1e-3), (1e-8, 5e-6)])
 def test_svd_accuracy_late_in_training(stop2, tol):
     """The Jacobi iteration stops early once its rotations are small (tnml_set_svd_stop); late in training
@@ -364,6 +368,7 @@ def test_svd_accuracy_late_in_training(stop2, tol):
         return B.reshape(ml * D, D * mr * L) if not left else np.transpose(B, (0, 1, 4, 2, 3)).reshape(ml * D * L, D * mr)
 
     worst_prod = worst_sig = 0.0
+    prods = []
     for ps in range(8):
         ctx.forward(want_f=False)
         left = ctx.l_pos == N - 1
@@ -385,12 +390,17 @@ def test_svd_accuracy_late_in_training(stop2, tol):
             prod = np.einsum('adkl,kec->adecl', A, C) if A.ndim == 4 else np.einsum('adk,kecl->adecl', A, C)
             U, S, Vh = np.linalg.svd(Bm, full_matrices=False)
             best = (U[:, :m] * S[:m]) @ Vh[:m]
-            worst_prod = max(worst_prod, np.abs(matricize(prod, left) - best).max() / np.abs(Bm).max())
+            prods.append(np.abs(matricize(prod, left) - best).max() / np.abs(Bm).max())
+            worst_prod = max(worst_prod, prods[-1])
             worst_sig = max(worst_sig, (np.abs(sig[:m] - S[:m]) / S[0]).max())
         ctx.debug_enable(False)
-    print('svd_stop2', stop2, 'worst product error %.2e, worst kept sigma error %.2e' % (worst_prod, worst_sig))
+    med, p90 = float(np.median(prods)), float(np.percentile(prods, 90))
+    print('svd_stop2', stop2, 'product error: worst %.2e, median %.2e, 90th percentile %.2e; worst kept sigma error %.2e' % (worst_prod, med, p90, worst_sig))
     assert worst_prod < tol
     assert worst_sig < tol
+    # the worst step is a tail statistic of a chaotic trajectory (it moved between 2.6e-6 and 2.6e-5 over builds that differ only
+    # in the rounding order of float64 sums); the bulk of the distribution does not move and is held much tighter
+    assert med < MED_TOL[stop2][0] and p90 < MED_TOL[stop2][1]
     ctx.close()
 
 
