@@ -158,63 +158,93 @@ __global__ __launch_bounds__(kChainThreads) void env_chain_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// The same chain on the matrix cores (round 3), for bonds <= 32: ONE WAVE owns 16 samples and walks all sites alone -- no
-// workgroup barrier anywhere.  Per site
+// The same chain on the matrix cores (round 3), for bonds <= 32: sixteen samples per workgroup, ONE wave walks all sites and never
+// meets a workgroup barrier.  Per site
 //     env_out[s][o] = sum_{(in, d)} (env_in[s][in] x[s][d]) A[(in, d)][o]                    v_mfma_f32_16x16x4_f32
 // with the samples as rows: A-operand lane (s = lane & 15, q = lane >> 4) holds, for k-step ks, row index (in, d) = 4 ks + q, i.e.
-// in = 2 ks + (q >> 1), d = q & 1 -- the lane keeps its environment values env[s][2 ks + (q >> 1)] in registers and multiplies them by
-// its ONE feature value x[s][q & 1].
-//   * The plain-FMA kernel above spends its 1.8 us per site waiting for memory: every workgroup of the chip needs the same core at
-//     the same time, and the features x[site][sample] of consecutive sites lie 40 KB apart.  Here a lane requests its feature
-//     values of EIGHT sites at once, eight sites ahead; the cores of the block of eight sites two blocks ahead are touched (one
-//     dword per 128-byte line, result folded into a value nobody reads) so that they sit in this XCD's L2 when they are wanted.
-//   * The core of site i + 1 (<= 8 KB) is requested as it lies in memory (16-byte loads, <= 8 per lane) before site i is computed
-//     and written to the other half of a double-buffered LDS area after it; the B operands are LDS reads through the core's strides.
-//   * The result tile (rows = samples 4 q + reg, column o = lane & 15) leaves as ONE 16-byte store per lane and column tile (four
-//     consecutive samples of bond index o: the environment stack is [bond][sample]) and is turned into the next site's A-operand
-//     layout through a 2 KB LDS tile (written and read by the same wave: in order, no barrier).
-// The plain-FMA kernel remains for bonds > 32 and for the renormalising calibration pass.
+// in = 2 ks + (q >> 1), d = q & 1; the result tile (rows = samples 4 q + reg, column o = lane & 15) leaves as ONE 16-byte store per
+// lane and column tile (the environment stack is [bond][sample]) and is turned into the next site's A-operand layout through a
+// 2 KB LDS tile (written and read by the same wave: in order, no barrier).
+// A single in-order wave pays 4-8 cycles for every instruction it issues (nothing else runs on its SIMD).  The first form of this
+// kernel (one wave doing everything: 0.66 ms per 784-site C3 chain against 1.44 ms for the plain-FMA kernel) spent more than half
+// of a site's ~2000 cycles on operand staging: core loads and their address arithmetic, the copy into LDS, twenty strided LDS reads.
+// The vector-memory counter of gfx950 also retires IN ORDER, so a far-ahead request issued by the computing wave would put the
+// latency of HBM on its very next wait.  Hence a workgroup of five waves with three jobs:
+//   wave 0 (computes)  per site: waits for the loader's flag, reads its B operands (NT x NKS values at consecutive 256-byte
+//                      offsets from one base register) and its feature value, multiplies the environment tile of the previous
+//                      site into A operands, 2 NT chains of MFMAs, stores the environment (16 bytes per lane and tile) and writes
+//                      the tile to LDS for the next site.  No loads from memory at all: its stores are never waited for.
+//   waves 1..3 (load)  each takes every third site, together up to kChainRing - 1 sites ahead: core as it lies in memory (16-byte
+//                      loads, requested one own site ahead) -> staging area -> gathered into the operand layout
+//                      [tile][k-step][lane] of a ring slot, zeroed where a row / column lies outside the core (so the computing
+//                      wave masks nothing); the lane's feature value.  (One loader kept the computing wave waiting: 0.76 ms; two
+//                      0.61; three 0.55, where the loaders wait for ring room 1100 of their 5000 cycles per own site.)
+//   wave 4 (warms L2)  touches one dword of every 128-byte line the loaders will want (cores, this workgroup's features) four
+//                      blocks of eight sites ahead, paced by the progress word.
+// Measured (tools/ubench/chain_bench.hip, -DTNML_CHAIN_STAMPS): the computing wave waits 240 cycles per site (the LDS round trip of
+// its flag poll) and spends ~1450 on the site: 640 MFMA issue, the rest the serial tail accumulators -> tile -> rows -> times x.
+// Two traps: a RELEASE store of a hand-off word also waits for the wave's GLOBAL stores / loads in flight (a trip to memory per
+// site): the words are stored relaxed behind an explicit wait for the LDS counter; a scalar load shares that counter, so the site
+// descriptor is requested one site ahead.
+// Hand-offs are LDS words that only grow (sites ready / sites consumed); a wave that waits 2^22 polls sets the abort word and
+// every wave leaves.
 // ------------------------------------------------------------------------------------------
 constexpr int kChainLD = 36;            // row stride of the wave's result tile (16-byte reads along a row of bond indices)
-constexpr int kChainCoreMax = 32 * kD * 32;
-constexpr int kChainBlock = 8;          // sites per feature request
-// NV4 = 16-byte loads per lane that cover the largest core of the chain (host: 1, 2, 4 or 8); every site issues all of them
-// (clamped addresses), so that the staging registers never become a stack array.
-//
-// The vector-memory counter of gfx950 retires IN ORDER: a wait for the core requested one site ago is also a wait for everything
-// requested before it.  A far-ahead request issued by the computing wave itself (features eight sites ahead, cache warming) would
-// therefore put the latency of HBM on the very next wait.  So the far-ahead requests belong to a SECOND wave of the workgroup that
-// computes nothing: it touches one dword of every 128-byte line the computing wave will want (cores and this workgroup's
-// features) a few blocks of eight sites ahead of it, paced by a progress word in LDS, and the computing wave's own requests -- one
-// site ahead -- find their data in the L2 of the XCD.
+constexpr int kChainBlock = 8;          // sites per block of cache-warming requests
 #ifdef TNML_CHAIN_STAMPS
 __device__ unsigned long long g_chain_stamps[16];
-#define TNML_STAMP(k) { __builtin_amdgcn_sched_barrier(0); if (i == 400 && blockIdx.x == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_[k] = __builtin_amdgcn_s_memtime(); } __builtin_amdgcn_sched_barrier(0); }
-#define TNML_STAMP_OUT() if (i == 401 && blockIdx.x == 7 && lane == 0) { for (int k = 0; k < 7; ++k) g_chain_stamps[k] = st_[k]; g_chain_stamps[7] = __builtin_amdgcn_s_memtime(); }
-#else
-#define TNML_STAMP(k)
-#define TNML_STAMP_OUT()
 #endif
-// NKS = k-steps of 4 rows (in, d) every site runs (covers the largest bond; av is zero beyond a site's own n_in), NT = column tiles
+constexpr int kChainRing = 4;
+#ifndef TNML_CHAIN_LOADERS
+#define TNML_CHAIN_LOADERS 3
+#endif
+constexpr int kChainLoaders = TNML_CHAIN_LOADERS;          // loader waves (each takes every kChainLoaders-th site); kChainRing >= kChainLoaders + 1
+__device__ inline bool chain_wait(const int *flag, int want, int *abort_word) {
+  for (int spin = 0; spin < (1 << 22); ++spin) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) { asm volatile("" ::: "memory"); return true; }
+    if ((spin & 255) == 255 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return false;
+}
+
+#ifdef TNML_CHAIN_STAMPS
+#define TNML_RSTAMP_BEGIN() rs0_ = __builtin_amdgcn_s_memtime()
+#define TNML_RSTAMP_END(k) { if (blockIdx.x == 7 && lane == 0) { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - rs0_; if ((k) == 0 || role == 1) atomicAdd(&g_chain_stamps[8 + (k)], d_); } }
+#else
+#define TNML_RSTAMP_BEGIN()
+#define TNML_RSTAMP_END(k)
+#endif
 template <int NV4, int NT, int NKS>
-__global__ __launch_bounds__(128) void env_chain_mfma_kernel(const ChainSite *__restrict__ sites, int n_sites, const float *__restrict__ cores,
-                                                             const float *__restrict__ labcore, const float *__restrict__ X,
-                                                             float *__restrict__ env_base, float *__restrict__ f, int b_pad) {
-  __shared__ __attribute__((aligned(16))) float sC[2][kChainCoreMax];
+__global__ __launch_bounds__(64 * (kChainLoaders + 2)) void env_chain_roles_kernel(const ChainSite *__restrict__ sites, int n_sites, const float *__restrict__ cores,
+                                                              const float *__restrict__ labcore, const float *__restrict__ X,
+                                                              float *__restrict__ env_base, float *__restrict__ f, int b_pad) {
+  __shared__ __attribute__((aligned(16))) float sRawAll[kChainLoaders][NV4 * 256];
+  __shared__ __attribute__((aligned(16))) float sB[kChainRing][NT * NKS * 64];
+  __shared__ float sXr[kChainRing][64];
   __shared__ __attribute__((aligned(16))) float sE[16 * kChainLD];
-  __shared__ int sProg;
-  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  __shared__ int sReadyS[kChainRing], sDone, sAbort;
+  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
   const int s0 = blockIdx.x * 16;
-  if (threadIdx.x >= 64) {
-    // ---- the warming wave ----
+  const int half = q >> 1, dsel = q & 1;
+#ifdef TNML_CHAIN_STAMPS
+  unsigned long long rs0_ = 0;
+#endif
+  if (threadIdx.x < kChainRing) sReadyS[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { sDone = 0; sAbort = 0; }
+  for (int e = threadIdx.x; e < 16 * kChainLD; e += 64 * (kChainLoaders + 2)) sE[e] = 0.f;
+  __syncthreads();
+
+  if (role == kChainLoaders + 1) {
+    // ---- last wave: cache warming ----
     float warm = 0.f;
     for (int i0 = 0; i0 < n_sites; i0 += kChainBlock) {
       for (int spin = 0; spin < (1 << 16); ++spin) {
-        if (i0 <= __hip_atomic_load(&sProg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 3 * kChainBlock) break;
+        if (i0 <= __hip_atomic_load(&sDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 4 * kChainBlock) break;
         __builtin_amdgcn_s_sleep(16);
       }
       float w[kChainBlock + 1];
-      // features: the 16 samples of this workgroup are one 128-byte line per site
       w[kChainBlock] = X[((size_t)sites[min(i0 + (lane & (kChainBlock - 1)), n_sites - 1)].x_site * b_pad + s0) * kD];
 #pragma unroll
       for (int j = 0; j < kChainBlock; ++j) {
@@ -227,120 +257,144 @@ __global__ __launch_bounds__(128) void env_chain_mfma_kernel(const ChainSite *__
     if (n_sites < 0) f[lane] = warm;      // never taken: keeps the loads alive
     return;
   }
-  // ---- the computing wave ----
-  // Everything a site needs is in registers when the site starts: its A operands av[ks] = env[s = r][in = 2 ks + half] x[s][dsel]
-  // and its B operands bv[t][ks] = A[(in, dsel)][o = 16 t + r] were read from LDS at the end of the previous site.  Rows of the
-  // last k-step that lie beyond n_in meet av == 0 (columns beyond n_out are written to the hand-over tile as zeros) and finite
-  // B values (the LDS area is zero-filled at the start and only ever holds core elements), so nothing has to be masked there.
-  // A single wave has nobody to hide its VALU instructions behind, so the site loop keeps them few: the LDS offsets of the B
-  // operands depend on the core's strides only and are kept in registers until a site with other strides comes (chain ends); the
-  // loop is unrolled by two so that the LDS half a site reads is an immediate offset.
-  const int half = q >> 1, dsel = q & 1;
-  for (int e = lane; e < 2 * kChainCoreMax; e += 64) sC[0][e] = 0.f;
-  for (int e = lane; e < 16 * kChainLD; e += 64) sE[e] = 0.f;
-  fvec4 pre[NV4];                         // the core of the NEXT site on its way from memory to LDS
-#define TNML_CORE_LOAD(c)                                                                                          \
-  {                                                                                                                \
-    const fvec4 *src_ = reinterpret_cast<const fvec4 *>(((c).is_label ? labcore : cores) + (c).core_off);          \
-    const int n4_ = ((c).n_in * kD * (c).n_out + 3) >> 2;                                                          \
-    _Pragma("unroll") for (int u = 0; u < NV4; ++u) pre[u] = src_[min(lane + 64 * u, n4_ - 1)];                    \
-  }
-#define TNML_CORE_PUT(dst)                                                                                         \
-  _Pragma("unroll") for (int u = 0; u < NV4; ++u) reinterpret_cast<fvec4 *>(dst)[lane + 64 * u] = pre[u];
-#define TNML_X_AT(c) X[((size_t)(c).x_site * b_pad + s0 + r) * kD + dsel]
-  int boff[NT][NKS];              // LDS offsets (bytes, within a half) of this lane's B operands
-#define TNML_B_OFFSETS(c)                                                                                          \
-  {                                                                                                                \
-    const int base_ = dsel * (c).s_d + half * (c).s_in, step_ = 2 * (c).s_in;                                      \
+
+  if (role >= 1) {
+    // ---- loader wave l = role - 1: operands of its sites j = l, l + kChainLoaders, ... into ring slot j % kChainRing ----
+    float *sRaw = sRawAll[role - 1];
+    fvec4 pre[NV4];
+    float xpre;
+    int goff[NT][NKS];                    // byte offsets into the staging area; -1: outside the core (operand 0)
+#define TNML_LOAD_SITE(c)                                                                                          \
+    {                                                                                                              \
+      const fvec4 *src_ = reinterpret_cast<const fvec4 *>(((c).is_label ? labcore : cores) + (c).core_off);        \
+      const int n4_ = ((c).n_in * kD * (c).n_out + 3) >> 2;                                                        \
+      _Pragma("unroll") for (int u = 0; u < NV4; ++u) pre[u] = src_[min(lane + 64 * u, n4_ - 1)];                  \
+      xpre = X[((size_t)(c).x_site * b_pad + s0 + r) * kD + dsel];                                                 \
+    }
+#define TNML_GATHER_OFFSETS(c)                                                                                     \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                               \
-      const int bo_ = base_ + min(16 * t + r, (c).n_out - 1) * (c).s_out;                                          \
-      _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) boff[t][ks] = 4 * min(bo_ + ks * step_, kChainCoreMax - 1); \
-    }                                                                                                              \
+      const int o_ = 16 * t + r;                                                                                   \
+      _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                                         \
+        const int in_ = 2 * ks + half;                                                                             \
+        goff[t][ks] = (in_ < (c).n_in && o_ < (c).n_out) ? 4 * (dsel * (c).s_d + in_ * (c).s_in + o_ * (c).s_out) : -1; \
+      }                                                                                                            \
+    }
+    const int j0 = role - 1;
+    if (j0 >= n_sites) return;
+    ChainSite cs = sites[j0], cn = sites[min(j0 + kChainLoaders, n_sites - 1)];
+    TNML_LOAD_SITE(cs);
+    TNML_GATHER_OFFSETS(cs);
+    for (int j = j0; j < n_sites; j += kChainLoaders) {
+      // the core of site j is in `pre` (requested one site ago); room in the ring?
+      TNML_RSTAMP_BEGIN();
+      if (j >= kChainRing && !chain_wait(&sDone, j - kChainRing + 1, &sAbort)) return;
+      TNML_RSTAMP_END(1);
+      TNML_RSTAMP_BEGIN();
+#pragma unroll
+      for (int u = 0; u < NV4; ++u) reinterpret_cast<fvec4 *>(sRaw)[lane + 64 * u] = pre[u];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TNML_RSTAMP_END(2);
+      const float xj = xpre;
+      const ChainSite c2 = sites[min(j + 2 * kChainLoaders, n_sites - 1)];
+      if (j + kChainLoaders < n_sites) { TNML_LOAD_SITE(cn); }     // travels while this site is gathered
+      float *slot = sB[j & (kChainRing - 1)];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const int off = goff[t][ks];
+          const float v = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sRaw) + max(off, 0));
+          slot[(t * NKS + ks) * 64 + lane] = off >= 0 ? v : 0.f;
+        }
+      sXr[j & (kChainRing - 1)][lane] = xj;
+      // (a RELEASE store would also wait for this wave's loads of the next core -- `vmcnt(0)` -- only the LDS writes above matter)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __hip_atomic_store(&sReadyS[j & (kChainRing - 1)], j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (j + kChainLoaders < n_sites) {
+        if (cn.s_in != cs.s_in || cn.s_d != cs.s_d || cn.s_out != cs.s_out || cn.n_out != cs.n_out || cn.n_in != cs.n_in) { TNML_GATHER_OFFSETS(cn); }
+        cs = cn; cn = c2;
+      }
+    }
+#undef TNML_LOAD_SITE
+#undef TNML_GATHER_OFFSETS
+    return;
   }
-#define TNML_B_READ(HALF)                                                                                          \
-  _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) bv[t][ks] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sC[HALF]) + boff[t][ks]);
+
+  // ---- wave 0: the chain ----
+  // Per site, ONE block of straight-line code holds the MFMAs of this site AND the LDS reads of the next site's operands (the loader
+  // is normally a site or more ahead: its flag is polled before the block), so that the reads travel in the shadow of the matrix
+  // pipeline; what remains serial is: accumulators -> environment store + tile to LDS -> tile back as rows -> times the feature.
   int soff[NT];                           // this lane's place in an environment slot: [bond o = 16 t + r][samples s0 + 4 q ..]
 #pragma unroll
   for (int t = 0; t < NT; ++t) soff[t] = (16 * t + r) * b_pad + s0 + 4 * q;
-  ChainSite cs = sites[0], c1 = sites[min(1, n_sites - 1)];
-  TNML_CORE_LOAD(cs);
-  float av[NKS], bv[NT][NKS];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) bv[t][ks] = 0.f;
+  float av[NKS], bv[NT][NKS], bvn[NT][NKS];
+  if (!chain_wait(&sReadyS[0], 1, &sAbort)) return;
   {
-    const float x0 = TNML_X_AT(cs);
+    const float x0 = sXr[0][lane];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) av[ks] = 0.f;
     if (half == 0) av[0] = x0;            // the chain starts from the scalar 1 (n_in == 1)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) bv[t][ks] = sB[0][(t * NKS + ks) * 64 + lane];
   }
-  TNML_CORE_PUT(sC[0]);
-  TNML_B_OFFSETS(cs);
-  TNML_B_READ(0);
-#ifdef TNML_CHAIN_STAMPS
-  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-  // one site; PAR = i & 1 is the LDS half its core lies in (compile time)
-#define TNML_SITE(PAR)                                                                                             \
+  // what the computing wave needs of a site's descriptor, requested one site ahead (a scalar load shares its counter with the LDS
+  // reads: requested where it is used it put a trip to L2 on every site)
+  int cur_nout = sites[0].n_out, nxt_nout = sites[min(1, n_sites - 1)].n_out;
+  long long cur_off = sites[0].env_out_off, nxt_off = sites[min(1, n_sites - 1)].env_out_off;
+  // one site; BV = this site's operand registers, BN = the next site's (the loop is unrolled by two so that they swap by name)
+#define TNML_ROLE_SITE(BV, BN)                                                                                     \
   {                                                                                                                \
     const bool more = i + 1 < n_sites;                                                                             \
-    TNML_STAMP(0);                                                                                                 \
-    const ChainSite c2 = sites[min(i + 2, n_sites - 1)];          /* wanted one site from now */                   \
-    float xnext = 0.f;                                                                                             \
-    if (more) { TNML_CORE_LOAD(c1); xnext = TNML_X_AT(c1); }       /* travel while this site is computed */        \
-    if ((i & (kChainBlock - 1)) == 0) __hip_atomic_store(&sProg, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-    TNML_STAMP(1);                                                                                                 \
-        fvec4 acc[NT], acb[NT];               /* two accumulators per tile: four independent MFMA chains; no branch */ \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) { acc[t] = fvec4{0.f, 0.f, 0.f, 0.f}; acb[t] = fvec4{0.f, 0.f, 0.f, 0.f}; } \
-    _Pragma("unroll") for (int ks = 0; ks < NKS; ks += 2)                                                          \
+    const int n_out_i = cur_nout;                                                                                  \
+    const long long off_i = cur_off;                                                                               \
+    cur_nout = nxt_nout; cur_off = nxt_off;                                                                        \
+    nxt_nout = sites[min(i + 2, n_sites - 1)].n_out; nxt_off = sites[min(i + 2, n_sites - 1)].env_out_off;         \
+    TNML_RSTAMP_BEGIN();                                                                                           \
+    if (more && !chain_wait(&sReadyS[(i + 1) & (kChainRing - 1)], i + 2, &sAbort)) return;                         \
+    TNML_RSTAMP_END(0);                                                                                            \
+    const float *nslot = sB[(i + 1) & (kChainRing - 1)];                                                           \
+    /* NT == 2: one accumulator per tile, the tiles alternating (a chain's consecutive MFMAs are two issue slots apart: no */ \
+    /* stall); NT == 1: two accumulators over the k-steps */                                                       \
+    fvec4 acc[2];                                                                                                  \
+    acc[0] = fvec4{0.f, 0.f, 0.f, 0.f}; acc[1] = fvec4{0.f, 0.f, 0.f, 0.f};                                       \
+    _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                                           \
       _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                             \
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[t][ks], acc[t], 0, 0, 0);                         \
-        if (ks + 1 < NKS) acb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks + 1], bv[t][ks + 1], acb[t], 0, 0, 0); \
+        BN[t][ks] = nslot[(t * NKS + ks) * 64 + lane];          /* (a finished chain reads a stale slot: never used) */ \
+        const int ai = NT == 2 ? t : (ks & 1);                                                                     \
+        acc[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], BV[t][ks], acc[ai], 0, 0, 0);                       \
       }                                                                                                            \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] += acb[t];                                               \
-    TNML_STAMP(2);                                                                                                 \
-    /* the next core goes to the other half of the LDS area BEFORE this site's environment is stored: the wait */  \
-    /* for its loads (requested a whole site ago) must not also be a wait for stores issued a moment ago */        \
-    if (more) { TNML_CORE_PUT(sC[1 - PAR]); }                                                                      \
-    TNML_STAMP(3);                                                                                                 \
-    /* result: rows = samples 4 q + reg, column o = 16 t + r */                                                    \
-    float *out = cs.env_out_off >= 0 ? (env_base ? env_base + cs.env_out_off : nullptr) : f;                       \
+    }                                                                                                              \
+    const float xnext = sXr[(i + 1) & (kChainRing - 1)][lane];                                                     \
+    if (NT == 1) acc[0] += acc[1];                                                                                 \
+    float *out = off_i >= 0 ? (env_base ? env_base + off_i : nullptr) : f;                                         \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                               \
       const int o = 16 * t + r;                                                                                    \
-      const bool valid = o < cs.n_out;                                                                             \
-      if (out && valid) *reinterpret_cast<fvec4 *>(out + soff[t]) = acc[t];                                        \
-      /* the next site reads env[s][in = o] as av[ks] of the lanes with half == (o & 1), ks = o >> 1 */            \
+      if (out && o < n_out_i) *reinterpret_cast<fvec4 *>(out + soff[t]) = acc[t];                                  \
+      /* the next site reads env[s][in = o] as av[ks] of the lanes with half == (o & 1), ks = o >> 1 (columns beyond n_out */ \
+      /* are exact zeros: the loader zeroed those B operands) */                                                   \
       const int colp = (o & 1) * 16 + (o >> 1);                                                                    \
-      _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) sE[(4 * q + reg) * kChainLD + colp] = valid ? acc[t][reg] : 0.f; \
+      _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) sE[(4 * q + reg) * kChainLD + colp] = acc[t][reg];       \
     }                                                                                                              \
-    TNML_STAMP(4);                                                                                                 \
     if (more) {                                                                                                    \
       const fvec4 *erow = reinterpret_cast<const fvec4 *>(sE + r * kChainLD + half * 16);                          \
-      _Pragma("unroll") for (int k4 = 0; k4 < (NKS + 3) / 4; ++k4) {                                       \
+      _Pragma("unroll") for (int k4 = 0; k4 < (NKS + 3) / 4; ++k4) {                                               \
         const fvec4 v = erow[k4];                                                                                  \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) if (4 * k4 + e < NKS) av[4 * k4 + e] = v[e] * xnext;         \
       }                                                                                                            \
-      TNML_STAMP(5);                                                                                               \
-      if (c1.s_in != cs.s_in || c1.s_d != cs.s_d || c1.s_out != cs.s_out || c1.n_out != cs.n_out) { TNML_B_OFFSETS(c1); } \
-      TNML_B_READ(1 - PAR);                                                                                        \
     }                                                                                                              \
-    TNML_STAMP(6);                                                                                                 \
-    cs = c1; c1 = c2;                                                                                              \
-    TNML_STAMP_OUT();                                                                                              \
+    /* (this site's operands and the next site's are in registers: the loader may have slot i back) */            \
+    /* (not a RELEASE store: that waits for the environment stores too -- a trip to memory per site) */           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+    __hip_atomic_store(&sDone, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                             \
   }
   for (int i = 0; i < n_sites; ++i) {
-    TNML_SITE(0);
+    TNML_ROLE_SITE(bv, bvn);
     if (++i >= n_sites) break;
-    TNML_SITE(1);
+    TNML_ROLE_SITE(bvn, bv);
   }
-#undef TNML_SITE
-#undef TNML_CORE_LOAD
-#undef TNML_CORE_PUT
-#undef TNML_X_AT
-#undef TNML_B_OFFSETS
-#undef TNML_B_READ
+#undef TNML_ROLE_SITE
 }
 
 void launch_env_chain(const ChainSite *sites_dev, int n_sites, const float *cores, const float *labcore,
@@ -353,8 +407,8 @@ void launch_env_chain(const ChainSite *sites_dev, int n_sites, const float *core
                        n_sites, cores, labcore, X, env_base, f, b, b_pad, L, Mmax, logmax_out);
   else if (!force_plain && mo <= 32 && (Mmax & 1) == 0) {    // (core slots of an even bond capacity are 16-byte aligned: the cores travel as 16-byte loads)
     const int n4 = (Mmax * kD * mo + 3) / 4;
-    const dim3 grid(b_pad / 16), block(128);
-#define TNML_CHAIN_GO(NV4, NT, NKS) hipLaunchKernelGGL((env_chain_mfma_kernel<NV4, NT, NKS>), grid, block, 0, st, sites_dev, n_sites, cores, labcore, X, env_base, f, b_pad)
+    const dim3 grid(b_pad / 16), block(64 * (kChainLoaders + 2));
+#define TNML_CHAIN_GO(NV4, NT, NKS) hipLaunchKernelGGL((env_chain_roles_kernel<NV4, NT, NKS>), grid, block, 0, st, sites_dev, n_sites, cores, labcore, X, env_base, f, b_pad)
     (void)n4;
     if (mo <= 10) TNML_CHAIN_GO(1, 1, 5);
     else if (mo <= 16) TNML_CHAIN_GO(2, 1, 8);

@@ -219,7 +219,7 @@ hipError_t hipLaunchKernel(const void *fn, dim3 g, dim3 b, void **args, size_t s
   } else if (has("wide_step") || has("f_only_kernel")) {
     // (the MFMA kernel's grid carries D*D slice workgroups behind the nblk sample workgroups)
     check_wide(*(const WideParams *)args[0], has("wide_step_mfma_kernel") ? *(int *)args[2] : (int)g.x, has("f_only_kernel"));
-  } else if (has("env_chain_mfma_kernel")) {
+  } else if (has("env_chain_roles_kernel")) {
     check_chain(*(const ChainSite **)args[0], *(int *)args[1], *(const float **)args[2], *(const float **)args[3], *(const float **)args[4],
                 *(float **)args[5], *(float **)args[6], *(int *)args[7], 1);
     if ((int)g.x * 16 != *(int *)args[7]) die("chain grid %u x 16 samples != b_pad %d", g.x, *(int *)args[7]);

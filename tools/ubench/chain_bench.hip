@@ -71,9 +71,8 @@ int main(int argc, char **argv) {
   {
     unsigned long long st[16];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_chain_stamps), sizeof st);
-    printf("site 400 of workgroup 7, cycles (100 MHz counter x 24): top->loads issued %lld, ->MFMAs issued %lld, ->core in LDS %lld, ->stores+tile %lld, ->A operands %lld, ->B operands %lld; whole site (to the same point of site 401) %lld\n",
-           (long long)(st[1] - st[0]) * 24, (long long)(st[2] - st[1]) * 24, (long long)(st[3] - st[2]) * 24, (long long)(st[4] - st[3]) * 24, (long long)(st[5] - st[4]) * 24,
-           (long long)(st[6] - st[5]) * 24, (long long)(st[7] - st[6]) * 24);
+    printf("roles kernel, workgroup 7, cycles per site over all launches so far (%d chains): computing wave waits %.0f | loader 0 waits for ring room %.0f, per own site; core -> staging (incl. its load wait) %.0f per own site\n",
+           40 * 2 + 3, (double)st[8] / (83.0 * N), (double)st[9] / (83.0 * N / TNML_CHAIN_LOADERS), (double)st[10] / (83.0 * N / TNML_CHAIN_LOADERS));
   }
 #endif
   std::vector<float> f0((size_t)L * b_pad), f1((size_t)L * b_pad);
