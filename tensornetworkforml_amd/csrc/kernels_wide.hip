@@ -341,6 +341,7 @@ __global__ __launch_bounds__(64 * (kChainLoaders + 2)) void env_chain_roles_kern
   }
   // what the computing wave needs of a site's descriptor, requested one site ahead (a scalar load shares its counter with the LDS
   // reads: requested where it is used it put a trip to L2 on every site)
+  bool seen_next = false;
   int cur_nout = sites[0].n_out, nxt_nout = sites[min(1, n_sites - 1)].n_out;
   long long cur_off = sites[0].env_out_off, nxt_off = sites[min(1, n_sites - 1)].env_out_off;
   // one site; BV = this site's operand registers, BN = the next site's (the loop is unrolled by two so that they swap by name)
@@ -352,8 +353,11 @@ __global__ __launch_bounds__(64 * (kChainLoaders + 2)) void env_chain_roles_kern
     cur_nout = nxt_nout; cur_off = nxt_off;                                                                        \
     nxt_nout = sites[min(i + 2, n_sites - 1)].n_out; nxt_off = sites[min(i + 2, n_sites - 1)].env_out_off;         \
     TNML_RSTAMP_BEGIN();                                                                                           \
-    if (more && !chain_wait(&sReadyS[(i + 1) & (kChainRing - 1)], i + 2, &sAbort)) return;                         \
+    /* the flag of site i + 1 was read during site i - 1 (its LDS round trip hidden behind that site's MFMAs); poll only if it */ \
+    /* had not arrived then */                                                                                     \
+    if (more && !seen_next && !chain_wait(&sReadyS[(i + 1) & (kChainRing - 1)], i + 2, &sAbort)) return;           \
     TNML_RSTAMP_END(0);                                                                                            \
+    const int peek = __hip_atomic_load(&sReadyS[(i + 2) & (kChainRing - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     const float *nslot = sB[(i + 1) & (kChainRing - 1)];                                                           \
     /* NT == 2: one accumulator per tile, the tiles alternating (a chain's consecutive MFMAs are two issue slots apart: no */ \
     /* stall); NT == 1: two accumulators over the k-steps */                                                       \
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(64 * (kChainLoaders + 2)) void env_chain_roles_kern
       }                                                                                                            \
     }                                                                                                              \
     const float xnext = sXr[(i + 1) & (kChainRing - 1)][lane];                                                     \
+    seen_next = peek >= i + 3;                                                                                     \
     if (NT == 1) acc[0] += acc[1];                                                                                 \
     float *out = off_i >= 0 ? (env_base ? env_base + off_i : nullptr) : f;                                         \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                               \
