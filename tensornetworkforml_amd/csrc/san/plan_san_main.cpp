@@ -101,6 +101,116 @@ static void run(const Cfg &c, int mode) {
   fflush(stdout);
 }
 
+#define FAILS(call)                                                                           \
+  do {                                                                                        \
+    int rc_ = (call);                                                                         \
+    if (rc_ == TNML_OK) { fprintf(stderr, "%s:%d %s succeeded but must fail\n", __FILE__, __LINE__, #call); exit(1); } \
+  } while (0)
+
+// The entry points beside tnml_sweep (the three sub-steps as standalone calls, activation, inspection, capture, the per-kernel
+// timers) and the argument checks: every call plans its launches and copies through the same registry checks.
+static void run_entry_points(int N, int M, int b, int L) {
+  const int D = 2;
+  tnml_ctx *ctx = nullptr;
+  OK(tnml_create(&ctx, N, D, L, M, b, 0));
+  std::vector<int> bond = start_bonds(N, M, D, L);
+  size_t total = 0;
+  for (int i = 0; i < N; ++i) total += (size_t)(i == 0 ? 1 : M) * D * (i == N - 1 ? 1 : M) * (i == 0 ? L : 1);
+  std::vector<float> cores(total, 0.05f);
+  OK(tnml_set_cores(ctx, cores.data(), total, bond.data(), 0));
+  FAILS(tnml_set_cores(ctx, cores.data(), total - 1, bond.data(), 0));          // size does not match the bonds
+  FAILS(tnml_set_cores(ctx, cores.data(), total, bond.data(), N));              // label site out of range
+  std::vector<float> X((size_t)b * N * D, 0.5f), f((size_t)L * b), act((size_t)L * b), der((size_t)L * b);
+  std::vector<int> y(b, 0);
+  FAILS(tnml_forward(ctx, f.data()));                                           // no batch yet
+  OK(tnml_set_input(ctx, X.data(), nullptr, b));                                // forward-only batch
+  OK(tnml_forward(ctx, f.data()));
+  FAILS(tnml_sweep(ctx, 0, 1, 1, 1e-3f, 0.f, 0, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 1.f, TNML_TRUNC_FIXED, nullptr, nullptr));  // no labels
+  OK(tnml_set_labels(ctx, y.data(), b));
+  FAILS(tnml_set_labels(ctx, y.data(), b + 1));
+  double amax = 0;
+  OK(tnml_f_absmax(ctx, &amax));
+  OK(tnml_get_f(ctx, f.data()));
+  OK(tnml_set_f(ctx, f.data()));
+  OK(tnml_activation(ctx, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 0.5f, 0, act.data(), der.data()));
+  OK(tnml_activation(ctx, TNML_ACT_LINEAR, TNML_LOSS_MSE, 1.f, 1, nullptr, der.data()));
+  // update_B / compute_L2_reg on the product of the cores and on a given merged tensor, both directions where the label allows
+  const int ml = 1, mr = N > 2 ? M : 1;
+  const size_t nB = (size_t)ml * D * D * mr * L;
+  std::vector<float> B(nB, 0.01f);
+  std::vector<double> Bn(nB), grad(nB);
+  float met2[2];
+  double loss = 0;
+  OK(tnml_update_B(ctx, nullptr, 0, 1e-3f, 1e-3f, 1, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 1.f, Bn.data(), nB, met2));
+  OK(tnml_update_B(ctx, B.data(), 0, 1e-3f, 0.f, 0, TNML_ACT_LINEAR, TNML_LOSS_MSE, 1.f, Bn.data(), nB, nullptr));
+  FAILS(tnml_update_B(ctx, B.data(), 0, 1e-3f, 0.f, 0, TNML_ACT_LINEAR, TNML_LOSS_MSE, 1.f, Bn.data(), nB - 1, nullptr));    // capacity
+  FAILS(tnml_update_B(ctx, B.data(), 1, 1e-3f, 0.f, 0, TNML_ACT_LINEAR, TNML_LOSS_MSE, 1.f, Bn.data(), nB, nullptr));        // label at 0 cannot move left
+  OK(tnml_l2_term(ctx, B.data(), 0, 1e-3f, &loss, grad.data(), nB));
+  FAILS(tnml_l2_term(ctx, nullptr, 0, 1e-3f, &loss, grad.data(), nB));
+  FAILS(tnml_l2_term(ctx, B.data(), 0, 1e-3f, &loss, grad.data(), nB - 1));
+  // tensor_svd alone: one-workgroup shapes, the HBM-resident path, the limits
+  {
+    const int shapes[][3] = {{4, 6, 2}, {2 * M, 2 * M * L, M}, {2 * M * L, 2 * M, M}, {2 * M, 2 * M, 2 * M}, {2, 2 * M * L, 1}};
+    for (auto &sh : shapes) {
+      std::vector<float> mat((size_t)sh[0] * sh[1], 0.1f), US((size_t)sh[0] * sh[2]), SV((size_t)sh[2] * sh[1]);
+      std::vector<double> sig(sh[0] < sh[1] ? sh[0] : sh[1]);
+      OK(tnml_svd_split(ctx, mat.data(), sh[0], sh[1], sh[2], US.data(), SV.data(), sig.data()));
+      OK(tnml_svd_split(ctx, mat.data(), sh[0], sh[1], sh[2], US.data(), SV.data(), nullptr));
+    }
+    std::vector<float> mat(130 * 260, 0.1f), US(130 * 4), SV(4 * 260);
+    FAILS(tnml_svd_split(ctx, mat.data(), 130, 260, 4, US.data(), SV.data(), nullptr));   // short side beyond 128
+    FAILS(tnml_svd_split(ctx, mat.data(), 4, 6, 5, US.data(), SV.data(), nullptr));       // rank beyond the short side
+    FAILS(tnml_svd_split(ctx, mat.data(), 4, 6, 0, US.data(), SV.data(), nullptr));
+  }
+  // a captured step and the per-kernel timers on each launch form
+  for (int mode = 0; mode < 3; ++mode) {
+    OK(tnml_set_step_pipeline(ctx, mode != 1));
+    OK(tnml_set_narrow_path(ctx, mode == 2));
+    OK(tnml_forward(ctx, nullptr));
+    const int left = tnml_l_pos(ctx) == N - 1;
+    OK(tnml_debug_enable(ctx, 1));
+    OK(tnml_sweep(ctx, left, 1, 1, 1e-3f, 1e-3f, 1, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 0.1f, TNML_TRUNC_FIXED, met2, f.data()));
+    std::vector<double> cap((size_t)4 * M * M * L + 4096);
+    size_t got = 0;
+    for (int what = TNML_DBG_B; what <= TNML_DBG_L2_GRAD; ++what) OK(tnml_get_step_debug(ctx, what, cap.data(), cap.size(), &got));
+    FAILS(tnml_get_step_debug(ctx, TNML_DBG_B, cap.data(), 1, &got));
+    OK(tnml_debug_enable(ctx, 2));
+    OK(tnml_sweep(ctx, left, 1, 0, 1e-3f, 1e-3f, 1, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 0.1f, TNML_TRUNC_FIXED, nullptr, nullptr));
+    OK(tnml_debug_enable(ctx, 4));
+    OK(tnml_profile_enable(ctx, 1));
+    OK(tnml_sweep(ctx, left, N - 3 > 0 ? N - 3 : 0, 0, 1e-3f, 1e-3f, 1, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 0.1f, TNML_TRUNC_FIXED, nullptr, nullptr));
+    OK(tnml_debug_enable(ctx, 0));
+    OK(tnml_profile_enable(ctx, 2));
+    FAILS(tnml_sweep(ctx, left, 1, 0, 1e-3f, 1e-3f, 1, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 0.1f, TNML_TRUNC_FIXED, nullptr, nullptr));   // past the chain end
+    FAILS(tnml_sweep(ctx, !left, 1, 1, 1e-3f, 1e-3f, 1, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 0.1f, 99, nullptr, nullptr));                // unknown policy
+    double ms = 0, cnt[8], st[4];
+    long long launches = 0;
+    for (int which = 0; which <= 5; ++which) OK(tnml_profile_get(ctx, which, &ms, &launches));
+    OK(tnml_get_counters(ctx, cnt));
+    OK(tnml_svd_stats(ctx, 0, st));
+    OK(tnml_svd_stats_ex(ctx, 1, st, 4));
+    OK(tnml_profile_reset(ctx));
+    OK(tnml_profile_enable(ctx, 0));
+    // the environments a finished sweep leaves behind (Network.l_cum_contraction / r_cum_contraction)
+    std::vector<float> env((size_t)M * 2 * L * b);
+    int m = 0;
+    const int side = tnml_l_pos(ctx) == N - 1 ? TNML_SIDE_LEFT : TNML_SIDE_RIGHT;
+    OK(tnml_get_env(ctx, side, side == TNML_SIDE_LEFT ? 0 : N - 1, env.data(), env.size(), &m));
+    FAILS(tnml_get_env(ctx, side, N + 3, env.data(), env.size(), &m));
+    FAILS(tnml_get_env(ctx, side, side == TNML_SIDE_LEFT ? 0 : N - 1, env.data(), 1, &m));
+  }
+  OK(tnml_set_svd_stop(ctx, 1e-8));
+  FAILS(tnml_set_svd_stop(ctx, 1.0));
+  OK(tnml_set_trunc_threshold(ctx, 0.99));
+  FAILS(tnml_set_trunc_threshold(ctx, 1.5));
+  FAILS(tnml_marker(ctx, 0));
+  OK(tnml_marker(ctx, 3));
+  OK(tnml_scale_cores(ctx, 0.5));
+  OK(tnml_destroy(ctx));
+  printf("entry points N %d bond %d b %d L %d: ok\n", N, M, b, L);
+  fflush(stdout);
+}
+
 int main(int argc, char **argv) {
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
   // BASELINE.json's single-GPU configurations at their true sizes, both directions (two sweeps), plus ragged small shapes
@@ -120,6 +230,10 @@ int main(int argc, char **argv) {
     else if (cfgs[i].M == 50) run(cfgs[i], 5);
     if (cfgs[i].N < 100 || cfgs[i].M == 10) run(cfgs[i], 3);
   }
+  run_entry_points(9, 6, 50, 2);
+  run_entry_points(12, 20, 300, 3);
+  run_entry_points(6, 50, 64, 10);
+  run_entry_points(5, 64, 40, 2);
   san_stub_report();
   if (san_stub_launches("sweep_persist") < 1 || san_stub_launches("step_pipe_kernel") < 1 || san_stub_launches("big_jacobi") < 1 ||
       san_stub_launches("narrow_step_kernel") < 1) {
