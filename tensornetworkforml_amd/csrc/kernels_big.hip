@@ -25,9 +25,9 @@ namespace {
 constexpr int kBT = 256;   // threads of the element-wise kernels
 
 // ---- merged tensor B[h,dk,dk1,g,l] = sum_s lab(h,dk,s,l) pl(s,dk1,g)  (Network_class.py:484) ----------------
-__global__ __launch_bounds__(kBT) void big_merge_kernel(NarrowParams p, float *__restrict__ Bf) {
+__device__ inline void big_merge_body(const NarrowParams &p, float *__restrict__ Bf, int blk, int nblk) {
   const int D = kD, g = p.g, s = p.s, L = p.L;
-  for (int e = blockIdx.x * kBT + threadIdx.x; e < p.bsize; e += gridDim.x * kBT) {
+  for (int e = blk * kBT + threadIdx.x; e < p.bsize; e += nblk * kBT) {
     const int l = e % L;
     int q = e / L;
     const int g_ = q % g; q /= g;
@@ -51,6 +51,9 @@ __global__ __launch_bounds__(kBT) void big_merge_kernel(NarrowParams p, float *_
     for (; k < s; ++k) a0 = fma((double)la[k * p.lab.s_out], (double)pl[k * p.pl.s_in], a0);
     Bf[e] = (float)((a0 + a1) + (a2 + a3));
   }
+}
+__global__ __launch_bounds__(kBT) void big_merge_kernel(NarrowParams p, float *__restrict__ Bf) {
+  big_merge_body(p, Bf, blockIdx.x, gridDim.x);
 }
 
 // ---- T[e_, rest] = sum_a Nh[a, e_] B[a, rest]   (first half of Ln.B.Rn) --------------------------------------
@@ -217,6 +220,14 @@ struct BigJacobiArgs {
   double *VW;
   unsigned *prog;
   unsigned token;
+  // eigenvalue order, kept rank, sigma^(+-1/4) and the step's metrics: the tail of workgroup 0 (a launch of its own until round 3)
+  int keep_max;          // kept rank under the fixed / reference policy (= m)
+  double trunc_thr;      // > 0: adaptive truncation
+  int *m_out;
+  float *metrics;
+  const float *red;      // the four metric slots sit behind its Bs gradient elements
+  int Bs, L;
+  double *ws;            // capture block / workspace (sigma at 4 Bs, scalars at 4 Bs + kDbgSigma)
 };
 
 // A replay workgroup: sixteen vectors, one per wave (pair k on lane k, the tournament move by one-lane wave shifts, as the eigenvector
@@ -293,6 +304,63 @@ __device__ inline void big_replay_block(const BigJacobiArgs &a, int *sPoll) {
   if (have && k < np) {
     a.VW[(size_t)v * n + 2 * k] = top;
     a.VW[(size_t)v * n + 2 * k + 1] = bot;
+  }
+}
+
+// ---- eigenvalue order, kept rank, sigma^(+-1/2), metrics: the tail of the Jacobi workgroup --------------------------
+//   lam3: [0,128) eigenvalues by position, [128,256) sigma^(1/2) and [256,384) sigma^(-1/2) of the kept columns (out)
+//   info: [3] kept rank, [4..) position of the sp-th largest eigenvalue (out)
+//   sLam[n] holds the eigenvalues by position (LDS, written by the caller, barrier passed); sOrd[n], sM: LDS scratch
+__device__ inline void big_order_tail(const BigJacobiArgs &a, int sweeps, const double *sLam, int *sOrd, int *sM) {
+  const int tid = threadIdx.x, NT = blockDim.x, n = a.n, Bs = a.Bs;
+  double *lam3 = a.lam;
+  int *info = a.info;
+  for (int j = tid; j < n; j += NT) {
+    const double lj = sLam[j];
+    int rank = 0;
+    for (int i = 0; i < n; ++i) { const double li = sLam[i]; rank += (li > lj) || (li == lj && i < j); }
+    sOrd[rank] = j;
+    info[4 + rank] = j;
+    a.ws[4 * (size_t)Bs + rank] = sqrt(lj);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int me = a.keep_max;
+    if (a.trunc_thr > 0.0) {                       // adaptive truncation (see narrow_step_kernel)
+      double tot = 0.0;
+      for (int j = 0; j < n; ++j) tot += sqrt(sLam[sOrd[j]]);
+      double cum = 0.0;
+      int idx = 0;
+      bool found = false;
+      for (int j = 0; j < n && !found; ++j) {
+        cum += sqrt(sLam[sOrd[j]]);
+        if (cum / tot > a.trunc_thr) { idx = j; found = true; }
+      }
+      me = min(a.keep_max, idx + 1);
+      if (a.m_out) *a.m_out = me;
+    }
+    *sM = me;
+    info[3] = me;
+    double *sc = a.ws + 4 * (size_t)Bs + kDbgSigma;
+    sc[3] = (double)sweeps;
+    sc[4] = (double)n;
+    if (a.metrics) {
+      const double cnt = (double)a.red[Bs + 3];
+      const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
+      a.metrics[0] = (float)((double)a.red[Bs] * inv);
+      a.metrics[1] = (float)((double)a.red[Bs + 1] * inv / (double)a.L);
+      if (a.red[Bs + 2] != 0.f) atomicOr(a.status, 1);
+    }
+  }
+  __syncthreads();
+  const double lam_max = sLam[sOrd[0]];
+  const int me = *sM;
+  for (int sp = tid; sp < me; sp += NT) {
+    const double l_ = sLam[sOrd[sp]];
+    const bool ok = l_ > 1e-300 && l_ > 1e-30 * lam_max;
+    const double sq = ok ? sqrt(sqrt(l_)) : 0.0;
+    lam3[kBigMaxN + sp] = sq;
+    lam3[2 * kBigMaxN + sp] = ok ? 1.0 / sq : 0.0;
   }
 }
 
@@ -525,7 +593,16 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
       __hip_atomic_store(a.prog, (a.token << 12) | (unsigned)rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  for (int j = tid; j < n; j += NT) a.lam[j] = __builtin_amdgcn_ldexp(fmax(diag(Gc, j), 0.0), sc_exp);
+  // eigenvalues by position -> memory (the cores kernel) and LDS (their order, below)
+  double *sLam = (double *)(sFlag + 8);            // (2 n + 8 ints before it: 8-byte aligned)
+  int *sOrd = (int *)(sLam + kBigMaxN), *sM = sOrd + kBigMaxN;
+  for (int j = tid; j < n; j += NT) {
+    const double lj = __builtin_amdgcn_ldexp(fmax(diag(Gc, j), 0.0), sc_exp);
+    a.lam[j] = lj;
+    sLam[j] = lj;
+  }
+  __syncthreads();
+  big_order_tail(a, sweeps, sLam, sOrd, sM);
   if (tid == 0) {
     a.info[0] = rounds; a.info[1] = sweeps; a.info[2] = converged;
     if (a.counters) {
@@ -534,68 +611,6 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
       atomicAdd(a.counters + 2, (unsigned long long)rounds);
     }
     if (!converged) atomicOr(a.status, 2);
-  }
-}
-
-// ---- eigenvalue order, kept rank, sigma^(+-1/2), metrics (one small block) ---------------------------------------
-//   lam3: [0,128) eigenvalues by position (in), [128,256) sigma^(1/2) and [256,384) sigma^(-1/2) of the kept columns (out)
-//   info: [3] kept rank, [4..) position of the sp-th largest eigenvalue (out)
-__global__ __launch_bounds__(128) void big_order_kernel(NarrowParams p, double *__restrict__ lam3, int *__restrict__ info,
-                                                       double *__restrict__ ws) {
-  __shared__ double sLam[kBigMaxN];
-  __shared__ int sOrd[kBigMaxN];
-  __shared__ int sM;
-  const int tid = threadIdx.x, NT = 128;
-  const int D = kD, L = p.L, Bs = p.bsize;
-  const int r = D * p.h, c = D * p.g * L;
-  const int n = r <= c ? r : c;
-  for (int j = tid; j < n; j += NT) sLam[j] = lam3[j];
-  __syncthreads();
-  for (int j = tid; j < n; j += NT) {
-    const double lj = sLam[j];
-    int rank = 0;
-    for (int i = 0; i < n; ++i) { const double li = sLam[i]; rank += (li > lj) || (li == lj && i < j); }
-    sOrd[rank] = j;
-    info[4 + rank] = j;
-    ws[4 * (size_t)Bs + rank] = sqrt(lj);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int me = p.m;
-    if (p.trunc_thr > 0.0) {                       // adaptive truncation (see narrow_step_kernel)
-      double tot = 0.0;
-      for (int j = 0; j < n; ++j) tot += sqrt(sLam[sOrd[j]]);
-      double cum = 0.0;
-      int idx = 0;
-      bool found = false;
-      for (int j = 0; j < n && !found; ++j) {
-        cum += sqrt(sLam[sOrd[j]]);
-        if (cum / tot > p.trunc_thr) { idx = j; found = true; }
-      }
-      me = min(p.m, idx + 1);
-      if (p.m_out) *p.m_out = me;
-    }
-    sM = me;
-    info[3] = me;
-    double *sc = ws + 4 * (size_t)Bs + kDbgSigma;
-    sc[3] = (double)info[1];
-    sc[4] = (double)n;
-    if (p.metrics) {
-      const double cnt = (double)p.red[Bs + 3];
-      const double inv = cnt > 0 ? 1.0 / cnt : 0.0;
-      p.metrics[0] = (float)((double)p.red[Bs] * inv);
-      p.metrics[1] = (float)((double)p.red[Bs + 1] * inv / (double)L);
-      if (p.red[Bs + 2] != 0.f) atomicOr(p.status, 1);
-    }
-  }
-  __syncthreads();
-  const double lam_max = sLam[sOrd[0]];
-  for (int sp = tid; sp < sM; sp += NT) {
-    const double l_ = sLam[sOrd[sp]];
-    const bool ok = l_ > 1e-300 && l_ > 1e-30 * lam_max;
-    const double sq = ok ? sqrt(sqrt(l_)) : 0.0;
-    lam3[kBigMaxN + sp] = sq;
-    lam3[2 * kBigMaxN + sp] = ok ? 1.0 / sq : 0.0;
   }
 }
 
@@ -626,32 +641,60 @@ __global__ __launch_bounds__(kBT) void big_cores_kernel(NarrowParams p, const do
 }
 
 // ---- behind norm environment of the next step: Nh_new = Cb^T (Nh (x) 1_d) Cb -----------------------------------
-// 16 lanes share one output element and split its inner sum (the outputs alone are too few to fill the chip);
-// the partial sums meet by xor shuffles inside the 16-lane group, in a fixed order
-__global__ __launch_bounds__(kBT) void big_norm_T_kernel(NarrowParams p, const float *__restrict__ Cb, double *__restrict__ T2,
-                                                        const int *__restrict__ m_dev) {
-  const int D = kD, h = p.h, m = m_dev[0], DM = D * m;
-  const int sub = threadIdx.x & 15;
-  for (int e = (blockIdx.x * kBT + threadIdx.x) >> 4; e < h * DM; e += (gridDim.x * kBT) >> 4) {
-    const int j = e % DM, i = e / DM;
-    double acc = 0.0;
-    if (p.Nh) { for (int kk = sub; kk < h; kk += 16) acc += p.Nh[i * h + kk] * (double)Cb[(size_t)kk * DM + j]; }
-    else if (sub == 0) acc = (double)Cb[e];
-    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (sub == 0) T2[e] = acc;
+// ONE launch, a workgroup per output column j (until round 3: T2 = Nh . Cb and Cb^T . T2 as two launches, 5.9 + 5.5 us of pure
+// latency): column j of T2 needs all of Nh and column j of Cb only, column j of the result all of Cb and that column of T2 --
+// no workgroup waits for another.  Everything a thread will read from memory is requested before the first barrier (the operands of
+// the second product do not depend on the first), the sums are split in a fixed way: the same bits on every rank.
+constexpr int kNormH = 64, kNormX = 2 * kNormH, kNormM = 128;
+__global__ __launch_bounds__(kBT) void big_norm_kernel(NarrowParams p, const float *__restrict__ Cb, const int *__restrict__ m_dev) {
+  __shared__ double sN[kNormH * kNormH];
+  __shared__ float sC[kNormX];
+  __shared__ double sT[2][kNormX];
+  __shared__ double sO[4][kNormM];
+  const int D = kD, h = p.h, m = m_dev[0], hD = h * D, j = blockIdx.x, t = threadIdx.x;
+  if (j >= m) return;                                  // (the grid is sized for the cap; adaptive truncation may keep fewer)
+  const int q = t >> 6, lane = t & 63, XQ = (hD + 3) / 4;
+  float c2[kNormX / 4];                                // rows x = q XQ + u of column `lane` of Cb
+#pragma unroll
+  for (int u = 0; u < kNormX / 4; ++u) {
+    const int x = q * XQ + u;
+    c2[u] = (u < XQ && x < hD && lane < m) ? Cb[(size_t)x * m + lane] : 0.f;
   }
-}
-__global__ __launch_bounds__(kBT) void big_norm_out_kernel(NarrowParams p, const float *__restrict__ Cb, const double *__restrict__ T2,
-                                                          const int *__restrict__ m_dev) {
-  const int D = kD, h = p.h, m = m_dev[0];
-  const int sub = threadIdx.x & 15;
-  for (int e = (blockIdx.x * kBT + threadIdx.x) >> 4; e < m * m; e += (gridDim.x * kBT) >> 4) {
-    const int j = e % m, i = e / m;
-    double acc = 0.0;
-    for (int kk = sub; kk < h * D; kk += 16) acc += (double)Cb[(size_t)kk * m + i] * T2[(size_t)kk * m + j];
-    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (sub == 0) p.Nh_new[e] = acc;
+  if (t < hD) sC[t] = Cb[(size_t)t * m + j];
+  if (p.Nh) for (int e = t; e < h * h; e += kBT) sN[e] = p.Nh[e];
+  __syncthreads();
+  {                                                    // T2[x][j], x = (a', d): two halves of the sum over a
+    const int x = t & (kNormX - 1), half = t >> 7;
+    if (x < hD) {
+      const int ap = x / D, d = x - ap * D;
+      double acc = 0.0;
+      if (p.Nh) {
+        const int H2 = (h + 1) / 2, a1 = min(h, (half + 1) * H2);
+        for (int a = half * H2; a < a1; ++a) acc = fma(sN[ap * h + a], (double)sC[a * D + d], acc);
+      } else if (half == 0) acc = (double)sC[x];
+      sT[half][x] = acc;
+    }
   }
+  __syncthreads();
+  if (lane < m) {                                      // out[i][j], i = lane: four quarters of the sum over x
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < kNormX / 4; ++u) {
+      const int x = q * XQ + u;
+      if (u < XQ && x < hD) acc = fma((double)c2[u], sT[0][x] + sT[1][x], acc);
+    }
+    sO[q][lane] = acc;
+  }
+  for (int i = lane + 64; i < m; i += 64) {            // (kept ranks beyond 64: not on the training path)
+    double acc = 0.0;
+    for (int u = 0; u < XQ; ++u) {
+      const int x = q * XQ + u;
+      if (x < hD) acc = fma((double)Cb[(size_t)x * m + i], sT[0][x] + sT[1][x], acc);
+    }
+    sO[q][i] = acc;
+  }
+  __syncthreads();
+  for (int i = t; i < m; i += kBT) p.Nh_new[(size_t)i * m + j] = (sO[0][i] + sO[1][i]) + (sO[2][i] + sO[3][i]);
 }
 
 }  // namespace
@@ -659,7 +702,8 @@ __global__ __launch_bounds__(kBT) void big_norm_out_kernel(NarrowParams p, const
 size_t big_jacobi_lds_bytes(int n) {
   const int np = n / 2;
   const size_t nblk = (size_t)np * (np + 1) / 2;
-  return (8 * nblk + 8 * (size_t)np + 64) * sizeof(double) + (2 * (size_t)n + 8) * sizeof(int) + 16;
+  return (8 * nblk + 8 * (size_t)np + 64) * sizeof(double) + (2 * (size_t)n + 8) * sizeof(int) + 16 +
+         kBigMaxN * (sizeof(double) + sizeof(int)) + 16;       // + the order tail's eigenvalues, positions, kept rank
 }
 
 // Every launch of this path goes through big_launch: grid, block and dynamic-LDS sizes are validated against the
@@ -736,21 +780,22 @@ __global__ __launch_bounds__(256) void big_ext_kernel(const float *__restrict__ 
 //       dB_{k+1}[h', c] = sum_{i = (h, d)} A_k(h, d, h') Z_{k+1}[i][c],      c = (d', d'', g, l)                 
 //     one column and eight h' per thread, the core in LDS (16-byte broadcast reads); the four metric slots behind Z are carried
 //     over.  Fixed summation order: every rank gets the same bits.
-__global__ __launch_bounds__(64) void big_contract_kernel(const float *__restrict__ Z, CoreView A, int ncols, float *__restrict__ red) {
-  extern __shared__ __attribute__((aligned(16))) float sAc[];             // [(h, d)][h' padded to a multiple of 8]
-  const int hp = A.n_in, h = A.n_out, nI = hp * kD, HS = (h + 7) & ~7;
-  const int o0 = blockIdx.y * 8;
-  for (int e = threadIdx.x; e < nI * 8; e += 64) {                        // the eight columns of the core this workgroup uses
+//     `chunk`: which 64 columns this WAVE takes; `by`: which eight h'; all waves of the workgroup share `by` and stage the core together
+__device__ inline void big_contract_body(const float *__restrict__ Z, const CoreView &A, int ncols, float *__restrict__ red, float *sAc,
+                                         int chunk, int by, bool carry_metrics) {
+  const int hp = A.n_in, h = A.n_out, nI = hp * kD;
+  const int o0 = by * 8;
+  for (int e = threadIdx.x; e < nI * 8; e += blockDim.x) {                // the eight columns of the core this workgroup uses
     const int i = e >> 3, o = o0 + (e & 7);
     sAc[e] = o < h ? A.base[(size_t)(i >> 1) * A.s_in + (i & 1) * A.s_d + (size_t)o * A.s_out] : 0.f;
   }
-  (void)HS;
   __syncthreads();
-  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = chunk * 64 + lane;
   if (c < ncols) {
     float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
     int i = 0;
-    for (; i + 8 <= nI; i += 8) {                   // eight rows of Z in flight (one wave per workgroup: nothing else hides the latency)
+    for (; i + 8 <= nI; i += 8) {                   // eight rows of Z in flight (few waves per CU: nothing else hides the latency)
       float z[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) z[u] = Z[(size_t)(i + u) * ncols + c];
@@ -772,8 +817,24 @@ __global__ __launch_bounds__(64) void big_contract_kernel(const float *__restric
     for (int u = 0; u < 8; ++u)
       if (o0 + u < h) red[(size_t)(o0 + u) * ncols + c] = v[u];
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kMetricSlots)
-    red[(size_t)h * ncols + threadIdx.x] = Z[(size_t)nI * ncols + threadIdx.x];
+  if (carry_metrics && threadIdx.x < kMetricSlots) red[(size_t)h * ncols + threadIdx.x] = Z[(size_t)nI * ncols + threadIdx.x];
+}
+__global__ __launch_bounds__(64) void big_contract_kernel(const float *__restrict__ Z, CoreView A, int ncols, float *__restrict__ red) {
+  extern __shared__ __attribute__((aligned(16))) float sAc[];             // [(h, d)][8]
+  big_contract_body(Z, A, ncols, red, sAc, blockIdx.x, blockIdx.y, blockIdx.x == 0 && blockIdx.y == 0);
+}
+// The contraction and the merged tensor of the same step need nothing from each other: one launch, the contraction's workgroups
+// first (theirs is the longer latency chain), four column chunks each.
+__global__ __launch_bounds__(kBT) void big_front_kernel(NarrowParams p, float *__restrict__ Bf, const float *__restrict__ Z, CoreView A,
+                                                       int ncols, float *__restrict__ red, int ncx, int ncontract) {
+  extern __shared__ __attribute__((aligned(16))) float sAc[];
+  const int bid = blockIdx.x;
+  if (bid < ncontract) {
+    const int bx = bid % ncx, by = bid / ncx;
+    big_contract_body(Z, A, ncols, red, sAc, bx * (kBT / 64) + (int)(threadIdx.x >> 6), by, bid == 0);
+  } else {
+    big_merge_body(p, Bf, bid - ncontract, (int)gridDim.x - ncontract);
+  }
 }
 
 bool launch_big_ext(const float *Eprev, const float *x_km1, const float *x_k, const CoreView &A, int b_pad, float *Ecur, float *Pk,
@@ -800,7 +861,7 @@ bool launch_big_contract(const float *Zred, const CoreView &A, int ncols, float 
 // produces: the merged tensor and T = Nh^T . B.  The host may enqueue it on a second stream beside the batch kernel
 // (`prep_only`), and then asks the chain proper to skip it (`skip_prep`).
 bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check, bool prep_only, bool skip_prep,
-                       hipEvent_t after_update) {
+                       hipEvent_t after_update, const BigFront *front) {
   const int D = kD, Bs = p.bsize;
   const int r = D * p.h, c = D * p.g * p.L;
   const bool short_rows = r <= c;
@@ -821,8 +882,20 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
     hipLaunchKernelGGL(kern, g_, b_, l_, st, __VA_ARGS__);                        \
     if (!big_launch_done(#kern, check, g_, b_, l_)) return false;                 \
   } while (0)
+  if (front && (Bf || skip_prep)) {            // no merged tensor to form beside it: the contraction alone
+    if (!launch_big_contract(front->Z, front->A, front->ncols, front->red, st)) return false;
+    front = nullptr;
+  }
   if (!Bf) {
-    if (!skip_prep) BIG(big_merge_kernel, dim3(nbe), dim3(kBT), 0, p, s.Bf);
+    if (front) {
+      const int ncx = (front->ncols + kBT - 1) / kBT, ncontract = ncx * ((front->A.n_out + 7) / 8);
+      const size_t lds = (size_t)front->A.n_in * kD * 8 * sizeof(float);
+      if (front->A.n_out < 1 || front->ncols < 1) {
+        snprintf(g_big_err, sizeof g_big_err, "big_front_kernel: core %d x %d x %d, %d columns", front->A.n_in, kD, front->A.n_out, front->ncols);
+        return false;
+      }
+      BIG(big_front_kernel, dim3(ncontract + nbe), dim3(kBT), lds, p, s.Bf, front->Z, front->A, front->ncols, front->red, ncx, ncontract);
+    } else if (!skip_prep) BIG(big_merge_kernel, dim3(nbe), dim3(kBT), 0, p, s.Bf);
     Bf = s.Bf;
   }
   double *ws = p.dbg;                          // the capture block doubles as the workspace of this path
@@ -842,18 +915,19 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   a.G = s.gram; a.n = n; a.m = p.m; a.stop2 = p.svd_stop2; a.rotlog = s.rotlog; a.lam = s.lam; a.info = s.info;
   a.counters = p.counters; a.status = p.status;
   a.Bn = p.Bnew; a.len = len; a.si = si; a.sx = sx; a.VW = s.VW; a.prog = s.prog; a.token = p.token & 0xfffffu;
+  a.keep_max = p.m; a.trunc_thr = p.trunc_thr; a.m_out = p.m_out; a.metrics = p.metrics; a.red = p.red; a.Bs = Bs; a.L = p.L; a.ws = ws;
   // workgroup 0 iterates; workgroups 1.. replay its rotation log on the n unit vectors and the len columns of W while it does
   // (they need no LDS but share the launch's request: all of them resident beside the batch kernel of the next step, whose 157
   // workgroups leave 99 CUs)
   BIG(big_jacobi_kernel, dim3(1 + (n + len + 15) / 16), dim3(1024), big_jacobi_lds_bytes(n), a);
-  BIG(big_order_kernel, dim3(1), dim3(128), 0, p, s.lam, s.info, ws);
   BIG(big_cores_kernel, dim3(std::min(((n + len) * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, p, (const double *)s.lam,
       (const int *)s.info, (const double *)s.VW, s.Cb);
   if (p.Nh_new) {
-    const int nb2 = std::min((16 * p.h * D * p.m + kBT - 1) / kBT, 1024);
-    BIG(big_norm_T_kernel, dim3(nb2), dim3(kBT), 0, p, (const float *)s.Cb, s.T2, (const int *)(s.info + 3));
-    BIG(big_norm_out_kernel, dim3(std::min((16 * p.m * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, p, (const float *)s.Cb,
-        (const double *)s.T2, (const int *)(s.info + 3));
+    if (p.h > kNormH || p.m > kNormM) {
+      snprintf(g_big_err, sizeof g_big_err, "big_norm_kernel: behind bond %d, kept rank %d", p.h, p.m);
+      return false;
+    }
+    BIG(big_norm_kernel, dim3(p.m), dim3(kBT), 0, p, (const float *)s.Cb, (const int *)(s.info + 3));
   }
 #undef BIG
   return true;

@@ -255,6 +255,28 @@ hipError_t hipLaunchKernel(const void *fn, dim3 g, dim3 b, void **args, size_t s
     need(*(float **)args[3], ((size_t)A.n_out * nc + kMetricSlots) * 4, "big_contract: raw gradient");
     if (shm < (size_t)A.n_in * kD * 8 * 4) die("big_contract_kernel: %zu bytes of LDS", shm);
     if ((size_t)g.x * 64 < nc || (int)g.y * 8 < A.n_out) die("big_contract_kernel: grid (%u, %u) for %zu columns, %d rows", g.x, g.y, nc, A.n_out);
+  } else if (has("big_front_kernel")) {    // (NarrowParams, merged tensor out, Z, core view, ncols, red, ncx, ncontract)
+    const NarrowParams &n = *(const NarrowParams *)args[0];
+    check_narrow(n);
+    need(*(float **)args[1], (size_t)n.bsize * 4, "big_front: merged tensor");
+    const CoreView &A = *(const CoreView *)args[3];
+    const size_t nc = *(int *)args[4];
+    const int ncx = *(int *)args[6], ncontract = *(int *)args[7];
+    need(*(const float **)args[2], ((size_t)A.n_in * kD * nc + kMetricSlots) * 4, "big_front: Z");
+    need(A.base, view_extent(A, 1) * 4, "big_front: core");
+    need(*(float **)args[5], ((size_t)A.n_out * nc + kMetricSlots) * 4, "big_front: raw gradient");
+    if (shm < (size_t)A.n_in * kD * 8 * 4) die("big_front_kernel: %zu bytes of LDS", shm);
+    if ((size_t)ncx * 256 < nc || ncontract != ncx * ((A.n_out + 7) / 8) || (int)g.x <= ncontract)
+      die("big_front_kernel: grid %u, %d x %d contraction workgroups for %zu columns, %d rows", g.x, ncx, ncontract / (ncx ? ncx : 1), nc, A.n_out);
+    if ((size_t)A.n_out * nc != (size_t)n.bsize) die("big_front_kernel: gradient %d x %zu, merged tensor %d", A.n_out, nc, n.bsize);
+  } else if (has("big_norm_kernel")) {     // (NarrowParams, behind core [rows][m], kept rank on the device)
+    const NarrowParams &n = *(const NarrowParams *)args[0];
+    if (n.h > 64 || n.m > 128) die("big_norm_kernel: behind bond %d, kept rank %d", n.h, n.m);
+    need(*(const float **)args[1], (size_t)n.h * kD * n.m * 4, "big_norm: behind core");
+    need(*(const int **)args[2], 4, "big_norm: kept rank");
+    if (n.Nh) need(n.Nh, (size_t)n.h * n.h * 8, "big_norm: Nh");
+    need(n.Nh_new, (size_t)n.m * n.m * 8, "big_norm: Nh_new");
+    if ((int)g.x < n.m) die("big_norm_kernel: %u workgroups for %d columns", g.x, n.m);
   } else if (has("reduce_slabs")) {        // (slabs, nblk, slab_stride, n, red)
     const int nblk = *(int *)args[1], stride = *(int *)args[2], n = *(int *)args[3];
     if (n > stride) die("reduce_slabs: %d elements of a slab of %d", n, stride);

@@ -817,7 +817,8 @@ static int narrow_path(const tnml_ctx *c, int h, int g, int s, int L, int m) {
   return 1;
 }
 
-static int run_narrow(tnml_ctx *c, NarrowParams &n, int path, bool skip_prep = false, hipEvent_t after_update = nullptr) {
+static int run_narrow(tnml_ctx *c, NarrowParams &n, int path, bool skip_prep = false, hipEvent_t after_update = nullptr,
+                      const BigFront *front = nullptr) {
   if (path == 0) {
     size_t lds = narrow_lds_bytes(n.h, n.g, n.s, n.L, n.m);
     if (n.fused && !n.prep_ready) lds = std::max(lds, prep_slice_lds_bytes(n.h, n.g, n.s, n.L));   // slice workgroups ride along
@@ -829,7 +830,7 @@ static int run_narrow(tnml_ctx *c, NarrowParams &n, int path, bool skip_prep = f
   if (rc) return rc;
   n.dbg = c->dbg;                       // the capture block is this path's workspace
   n.token = ++c->token;                 // (tags the progress words of the replay that rides in the Jacobi launch)
-  if (!launch_narrow_big(n, c->big, c->stream, c->check_launches, false, skip_prep, after_update)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
+  if (!launch_narrow_big(n, c->big, c->stream, c->check_launches, false, skip_prep, after_update, front)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
   return TNML_OK;
 }
 
@@ -1454,9 +1455,11 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       }
       prof_begin(c);
       bool prep_done = false;
+      BigFront front{};
       if (zbig) {
-        // raw gradient = A_{k-1}^T . Z_k (+ the metric tail): no batch kernel, no slab reduction, no exchange on this stream
-        if (!launch_big_contract(c->zred, w.ext_core, D * D * g * L, c->red, c->stream)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
+        // raw gradient = A_{k-1}^T . Z_k (+ the metric tail): no batch kernel, no slab reduction, no exchange on this stream; it rides
+        // in the launch that forms the merged tensor (run_narrow below)
+        front.Z = c->zred; front.A = w.ext_core; front.ncols = D * D * g * L; front.red = c->red;
       } else if (!launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream, &prep_done))
         return fail(TNML_ERR_ARG, "step at sites (%d,%d): a 32-sample tile of this bond dimension does not fit the batch kernels' LDS", p, p + 1);
       n.prep_ready = prep_done ? 1 : 0;
@@ -1494,7 +1497,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
                  lds_z > 0 && lds_z <= 160 * 1024 && D * h <= 2 * c->Mmax && (size_t)D * h * c->b_pad <= (size_t)2 * c->Mmax * c->b_pad;
       }
       if (next_z && !c->bigPk) HIP_TRY(hipMalloc(&c->bigPk, (size_t)D * c->Mmax * c->b_pad * sizeof(float)));
-      { int rc = run_narrow(c, n, npath, prep_ahead, next_z ? c->ev_upd_big : nullptr); if (rc) return rc; }
+      { int rc = run_narrow(c, n, npath, prep_ahead, next_z ? c->ev_upd_big : nullptr, zbig ? &front : nullptr); if (rc) return rc; }
       prof_end(c, 3);
       if (zbig && !next_z) {
         // a step that took its gradient from Z launched no batch kernel, and none for the next step either: the behind environment
@@ -1530,7 +1533,9 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
         c->sweep_launches += 3;
         f_by_z = true;
       }
-      c->sweep_launches += (zbig ? 1 : (fused_now ? 2 : 3)) + (npath == 1 ? 11 : 0);
+      // batch kernel + reduction (a step fed by Z has neither: its contraction rides in the chain's first launch), then the update:
+      // one launch in LDS, eight through HBM (front, T, weight decay, update, Gram, Jacobi + replay + order, cores, norm environment)
+      c->sweep_launches += (zbig ? 0 : ((fused_now && npath == 0) ? 1 : 2)) + (npath == 1 ? 8 : 1);
       c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
       if (mode == 1) {
         // the behind environment list grew (as update_B does, Network_class.py:637-652); nothing else changes

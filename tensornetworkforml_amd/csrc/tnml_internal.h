@@ -181,15 +181,18 @@ struct BigScratch {
   int *info;          // rounds applied, sweeps, converged, kept rank, then the eigenvalue order [128]
   double *VW;         // [(rows + cols)][n]  V, then W^T V
   float *Cb;          // [rows][m]  new behind core, contiguous
-  double *T2;         // [rows][m]
+  double *T2;         // [rows][m]  (unused since the norm environment became one launch)
   unsigned *prog;     // [2] progress / final word of the replay that rides in the Jacobi launch (kernels_big.hip)
 };
 constexpr int kBigMaxN = 128;
 constexpr int kBigParts = 512;
 size_t big_jacobi_lds_bytes(int n);
 // false: a launch of the path was illegal or (check) failed; big_launch_error() names it
+// `front`: the raw gradient of a pipelined large-tensor step, red = A^T . Z, formed in the SAME launch as the merged tensor
+// (neither needs the other); without a merged tensor to form it is launched alone, in front of the chain
+struct BigFront { const float *Z; CoreView A; int ncols; float *red; };
 bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check, bool prep_only = false,
-                       bool skip_prep = false, hipEvent_t after_update = nullptr);
+                       bool skip_prep = false, hipEvent_t after_update = nullptr, const BigFront *front = nullptr);
 // pipelined large-tensor step: behind environment + (h, d) operand of the pre-gradient; raw gradient = A^T . Z (kernels_big.hip)
 bool launch_big_ext(const float *Eprev, const float *x_km1, const float *x_k, const CoreView &A, int b_pad, float *Ecur, float *Pk,
                     hipStream_t st);
