@@ -247,14 +247,15 @@ int tnml_timer_stop(tnml_ctx *ctx, double *elapsed_ms);
  *          3 update+SVD kernel (classic narrow kernel / the single launch of a pipelined step)
  * tnml_profile_enable(ctx, 2): one HIP event pair per tnml_sweep call, nothing waits inside the timed region
  *   which: 4 -> ms between first and last launch of all sweeps since the reset, launches = kernel launches they made
- *          5 -> the same ms, launches = number of single-launch (pipelined) steps among them */
+ *          5 -> the same ms, launches = number of pipelined steps among them (single-launch steps and large-tensor steps that
+ *               took their gradient from the pre-gradient the previous step's side stream left) */
 int tnml_profile_enable(tnml_ctx *ctx, int on);
 int tnml_profile_get(tnml_ctx *ctx, int which, double *ms, long long *launches);
 int tnml_profile_reset(tnml_ctx *ctx);
 /* Work done since the last tnml_profile_reset, computed from the dimensions of every step that ran:
  *   out8 = {sweep steps, algorithmic bytes of those steps (4 b (2h + g + 3D + 2L + 1) each: environments, features, f, labels),
  *           algorithmic flops (4 b D^2 h g L + 2 b D h^2 each), forward calls, algorithmic bytes of those forwards,
- *           kernel launches of the sweeps, single-launch (pipelined) steps among them,
+ *           kernel launches of the sweeps, pipelined steps among them (single-launch steps + large-tensor steps fed by Z),
  *           device ms inside the sweeps (0 unless tnml_profile_enable(ctx, 2) was on; read it through tnml_profile_get(4) first)} */
 int tnml_get_counters(tnml_ctx *ctx, double *out8);
 /* always-on counters of the SVD since the last reset: out3 = {Jacobi sweeps, number of SVDs, Jacobi rounds (one barrier each)} */

@@ -79,8 +79,39 @@ __global__ __launch_bounds__(kBT) void big_l2_T_kernel(NarrowParams p, const flo
   }
 }
 
-// ---- G = T . Ng, the weight-decay term, dv = raw - wdterm and the three block-partial sums --------------------
-//   ws layout (doubles): [0,Bs) B   [Bs,2Bs) dB_raw   [2Bs,3Bs) dv (later B_new)   [3Bs,4Bs) weight-decay term
+// ---- the weight-decay term, dv = raw - wdterm and the three block-partial sums ----------------------------------------
+//   ws layout (doubles): [0,Bs) B   [Bs,2Bs) dB_raw   [2Bs,3Bs) dv   [3Bs,4Bs) weight-decay term
+//   part: [nb][3] block partials; big_update_kernel sums them with big_sum_parts: every block and every rank in the same fixed order.
+//   (A last-arriver block that left the step length behind was tried: one agent-scope atomic per block on one address costs
+//   ~20 ns each, serialised -- 34 us at the 1563 blocks of a C5 step.)
+__device__ inline void big_wd_tail(double *__restrict__ part, double sumB, double sumD, double l2) {
+  __shared__ double red[3][kBT / 64];
+  for (int off = 32; off > 0; off >>= 1) { sumB += __shfl_xor(sumB, off); sumD += __shfl_xor(sumD, off); l2 += __shfl_xor(l2, off); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sumB; red[1][threadIdx.x >> 6] = sumD; red[2][threadIdx.x >> 6] = l2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0, c = 0;
+    for (int w = 0; w < kBT / 64; ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
+    part[3 * blockIdx.x] = a; part[3 * blockIdx.x + 1] = b; part[3 * blockIdx.x + 2] = c;
+  }
+}
+// sums of the partials, by all 256 threads of a workgroup (kBT): threads stride the partials, a fixed xor-shuffle tree per wave,
+// the four waves in order.  out3 (LDS) = {sum|B|, sum|dv|, L2 sum}; ends with a barrier.
+__device__ inline void big_sum_parts(const double *__restrict__ part, int nparts, double (*sRed)[kBT / 64], double *out3) {
+  double a_ = 0.0, b_ = 0.0, c_ = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBT) { a_ += part[3 * i]; b_ += part[3 * i + 1]; c_ += part[3 * i + 2]; }
+  for (int off = 32; off > 0; off >>= 1) { a_ += __shfl_xor(a_, off); b_ += __shfl_xor(b_, off); c_ += __shfl_xor(c_, off); }
+  if ((threadIdx.x & 63) == 0) { sRed[0][threadIdx.x >> 6] = a_; sRed[1][threadIdx.x >> 6] = b_; sRed[2][threadIdx.x >> 6] = c_; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0, c = 0;
+    for (int w = 0; w < kBT / 64; ++w) { a += sRed[0][w]; b += sRed[1][w]; c += sRed[2][w]; }
+    out3[0] = a; out3[1] = b; out3[2] = c;
+  }
+  __syncthreads();
+}
+
+// (a) from a merged tensor in memory and T = Nh^T . B (a given merged tensor; steps whose preparation ran ahead on the side stream)
 __global__ __launch_bounds__(kBT) void big_wd_kernel(NarrowParams p, const float *__restrict__ Bf, const double *__restrict__ T,
                                                     double *__restrict__ ws, double *__restrict__ part) {
   const int g = p.g, L = p.L, Bs = p.bsize;
@@ -116,31 +147,109 @@ __global__ __launch_bounds__(kBT) void big_wd_kernel(NarrowParams p, const float
     sumB += fabs(bv);
     sumD += fabs(dv);
   }
-  __shared__ double red[3][kBT / 64];
-  for (int off = 32; off > 0; off >>= 1) { sumB += __shfl_xor(sumB, off); sumD += __shfl_xor(sumD, off); l2 += __shfl_xor(l2, off); }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sumB; red[1][threadIdx.x >> 6] = sumD; red[2][threadIdx.x >> 6] = l2; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0, b = 0, c = 0;
-    for (int w = 0; w < kBT / 64; ++w) { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
-    part[3 * blockIdx.x] = a; part[3 * blockIdx.x + 1] = b; part[3 * blockIdx.x + 2] = c;
+  big_wd_tail(part, sumB, sumD, l2);
+}
+
+// (b) from the two cores: Ln.B.Rn = (Nh^T . lab) . (pl . Ng) contracted over the shared bond like the merged tensor itself -- the
+//     merged tensor B and the L2 gradient in ONE loop over s, no T = Nh^T . B in between (a launch of 100 k x 50-term sums less).
+//       NL[h', dk, s, l] = sum_a Nh[a, h'] lab(a, dk, s, l)       PR[s, dk1, f] = sum_c pl(s, dk1, c) Ng[c, f]
+//     are formed by big_front_kernel beside the contraction.
+//     A workgroup takes 64 elements per pass: waves 0 and 2 form the merged-tensor sums of 32 elements each, waves 1 and 3 the L2
+//     sums of the same elements (the role is wave-uniform: no divergence), two lanes per element splitting the shared bond; the
+//     halves meet by a lane shuffle, the L2 sum crosses to its element's owner through LDS.  (One lane per element with both sums in
+//     its loop: 23 us at C5 -- longer than the three launches it replaced; roles on lanes of the same wave: 38 us.)
+__global__ __launch_bounds__(kBT) void big_merge_wd_kernel(NarrowParams p, float *__restrict__ Bf, const double *__restrict__ NL,
+                                                          const double *__restrict__ PR, double *__restrict__ ws,
+                                                          double *__restrict__ part) {
+  __shared__ double sGV[64];
+  const int D = kD, g = p.g, sb = p.s, L = p.L, Bs = p.bsize;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int which = wave & 1, half = lane & 1, slot = 32 * (wave >> 1) + (lane >> 1);     // element slot of the pass, 0..63
+  const int SH = (sb + 1) / 2, k_lo = half * SH, k_hi = min(sb, k_lo + SH);
+  double sumB = 0.0, sumD = 0.0, l2 = 0.0;
+  for (int e0 = blockIdx.x * 64; e0 < Bs; e0 += gridDim.x * 64) {          // block-uniform trip count (barriers inside)
+    const int e = e0 + slot;
+    const bool live = e < Bs;
+    const int ee = live ? e : Bs - 1;
+    const int l = ee % L;
+    int q = ee / L;
+    const int g_ = q % g; q /= g;
+    const int dk1 = q % D; q /= D;
+    const int dk = q % D, h_ = q / D;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int k = k_lo;
+    if (which == 0) {
+      const float *la = p.lab.base + h_ * p.lab.s_in + dk * p.lab.s_d + l;
+      const float *pl = p.pl.base + dk1 * p.pl.s_d + g_ * p.pl.s_out;
+      for (; k + 8 <= k_hi; k += 8) {
+        float lv[8], pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { lv[u] = la[(k + u) * p.lab.s_out]; pv[u] = pl[(k + u) * p.pl.s_in]; }
+        a0 = fma((double)lv[0], (double)pv[0], a0); a1 = fma((double)lv[1], (double)pv[1], a1);
+        a2 = fma((double)lv[2], (double)pv[2], a2); a3 = fma((double)lv[3], (double)pv[3], a3);
+        a0 = fma((double)lv[4], (double)pv[4], a0); a1 = fma((double)lv[5], (double)pv[5], a1);
+        a2 = fma((double)lv[6], (double)pv[6], a2); a3 = fma((double)lv[7], (double)pv[7], a3);
+      }
+      if (k < k_hi) {                                     // the tail in one batch too (clamped index, masked product)
+        float lv[8], pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int kk = min(k + u, k_hi - 1); lv[u] = la[kk * p.lab.s_out]; pv[u] = pl[kk * p.pl.s_in]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k + u < k_hi) a0 = fma((double)lv[u], (double)pv[u], a0);
+      }
+    } else if (p.l2_flag) {
+      const double *nl = NL + ((size_t)(h_ * D + dk) * sb) * L + l;
+      const double *pr = PR + (size_t)dk1 * g + g_;
+      for (; k + 8 <= k_hi; k += 8) {
+        double nv[8], rv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { nv[u] = nl[(size_t)(k + u) * L]; rv[u] = pr[(size_t)(k + u) * D * g]; }
+        a0 = fma(nv[0], rv[0], a0); a1 = fma(nv[1], rv[1], a1); a2 = fma(nv[2], rv[2], a2); a3 = fma(nv[3], rv[3], a3);
+        a0 = fma(nv[4], rv[4], a0); a1 = fma(nv[5], rv[5], a1); a2 = fma(nv[6], rv[6], a2); a3 = fma(nv[7], rv[7], a3);
+      }
+      if (k < k_hi) {
+        double nv[8], rv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int kk = min(k + u, k_hi - 1); nv[u] = nl[(size_t)kk * L]; rv[u] = pr[(size_t)kk * D * g]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k + u < k_hi) a0 = fma(nv[u], rv[u], a0);
+      }
+    }
+    const double mine = (a0 + a1) + (a2 + a3);
+    const double other = __shfl_xor(mine, 1);
+    const double tot = half == 0 ? mine + other : other + mine;          // lower half of the bond first, on both lanes
+    if (which == 1 && half == 0) sGV[slot] = tot;
+    __syncthreads();
+    if (which == 0 && half == 0 && live) {
+      const float bf = (float)tot;                         // the merged tensor is a float32 tensor (as on the classic path)
+      Bf[e] = bf;
+      const double bv = (double)bf;
+      const double raw = (double)p.red[e];
+      double wdterm;
+      if (p.l2_flag) {
+        const double gv = sGV[slot];
+        l2 += bv * gv;
+        wdterm = 2.0 * (double)p.wd * gv;
+      } else {
+        wdterm = (double)p.wd * bv;
+      }
+      const double dv = raw - wdterm;
+      ws[e] = bv; ws[(size_t)Bs + e] = raw; ws[2 * (size_t)Bs + e] = dv; ws[3 * (size_t)Bs + e] = wdterm;
+      sumB += fabs(bv);
+      sumD += fabs(dv);
+    }
+    __syncthreads();                                       // (sGV is rewritten by the next pass)
   }
+  big_wd_tail(part, sumB, sumD, l2);
 }
 
 // ---- clip + update (Network_class.py:755-761); every block sums the partials in the same fixed order ----------
 __global__ __launch_bounds__(kBT) void big_update_kernel(NarrowParams p, double *__restrict__ ws, const double *__restrict__ part,
                                                         int nparts) {
   const int Bs = p.bsize;
-  // identical summation tree in every block and on every rank: lanes stride the partials, then a fixed
-  // xor-shuffle tree
   __shared__ double sSum[3];
-  if (threadIdx.x < 64) {
-    double a_ = 0.0, b_ = 0.0, c_ = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 64) { a_ += part[3 * i]; b_ += part[3 * i + 1]; c_ += part[3 * i + 2]; }
-    for (int off = 32; off > 0; off >>= 1) { a_ += __shfl_xor(a_, off); b_ += __shfl_xor(b_, off); c_ += __shfl_xor(c_, off); }
-    if (threadIdx.x == 0) { sSum[0] = a_; sSum[1] = b_; sSum[2] = c_; }
-  }
-  __syncthreads();
+  __shared__ double sRed[3][kBT / 64];
+  big_sum_parts(part, nparts, sRed, sSum);
   const double sumB = sSum[0], sumD = sSum[1], l2 = sSum[2];
   double factor = (double)p.lr;
   if (sumD > sumB) factor = (double)p.lr * (sumB / sumD);
@@ -164,16 +273,22 @@ __global__ __launch_bounds__(kBT) void big_update_kernel(NarrowParams p, double 
 
 // ---- Gram matrix of the short side, float64 accumulation of the float32 B_new -----------------------------------
 //   W(i, x) = Bn[i * si + x * sx];  G[i][j] = sum_x W(i,x) W(j,x), 16x16 output tile per block, upper tiles only
+//   (Applying the clipped step inside this launch was tried in round 3: it saves the update launch on this stream but the side stream,
+//   which waits for B_new, then starts 8 us later -- and its chain is as long as the Jacobi kernel: removed.)
 constexpr int kGramKS = 8;      // slices along the long index; the Jacobi kernel sums the partial matrices in slice order
 __global__ __launch_bounds__(256) void big_gram_kernel(const float *__restrict__ Bn, int n, int len, int si, int sx,
-                                                      double *__restrict__ Gpart) {
+                                                      double *__restrict__ Gpart, unsigned *sig_flag, unsigned sig_val) {
   const int ti = blockIdx.y, tj = blockIdx.x, ks = blockIdx.z;
+  // "B_new is ready" for the side stream (big_gate_kernel): this kernel starts when the update before it in the stream is complete and
+  // visible, so its first workgroup may say so at once -- a signal kernel of its own between the two costs this stream 5-6 us
+  if (sig_flag && ti == 0 && tj == 0 && ks == 0 && threadIdx.x == 0)
+    __hip_atomic_store(sig_flag, sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (ti > tj) return;
   __shared__ float sA[16][65], sB[16][65];
   const int r = threadIdx.x >> 4, cidx = threadIdx.x & 15;
   const int chunk = ((len + kGramKS - 1) / kGramKS + 63) & ~63;
   const int x_lo = ks * chunk, x_hi = min(len, x_lo + chunk);
-  double acc = 0.0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
   for (int x0 = x_lo; x0 < x_hi; x0 += 64) {
     for (int e = threadIdx.x; e < 16 * 64; e += 256) {
       const int row = e >> 6, x = e & 63;
@@ -182,10 +297,15 @@ __global__ __launch_bounds__(256) void big_gram_kernel(const float *__restrict__
       sB[row][x] = (ib < n && x0 + x < x_hi) ? Bn[(size_t)ib * si + (size_t)(x0 + x) * sx] : 0.f;
     }
     __syncthreads();
-#pragma unroll 16
-    for (int x = 0; x < 64; ++x) acc += (double)sA[r][x] * (double)sB[cidx][x];
+    // (four accumulators: a dependent float64 FMA costs 40 cycles; the sum is re-associated, in float64)
+#pragma unroll 4
+    for (int x = 0; x < 64; x += 4) {
+      acc0 = fma((double)sA[r][x], (double)sB[cidx][x], acc0); acc1 = fma((double)sA[r][x + 1], (double)sB[cidx][x + 1], acc1);
+      acc2 = fma((double)sA[r][x + 2], (double)sB[cidx][x + 2], acc2); acc3 = fma((double)sA[r][x + 3], (double)sB[cidx][x + 3], acc3);
+    }
     __syncthreads();
   }
+  const double acc = (acc0 + acc1) + (acc2 + acc3);
   const int i = ti * 16 + r, j = tj * 16 + cidx;
   double *G = Gpart + (size_t)ks * n * n;
   if (i < n && j < n && i <= j) { G[(size_t)i * n + j] = acc; G[(size_t)j * n + i] = acc; }
@@ -641,61 +761,34 @@ __global__ __launch_bounds__(kBT) void big_cores_kernel(NarrowParams p, const do
 }
 
 // ---- behind norm environment of the next step: Nh_new = Cb^T (Nh (x) 1_d) Cb -----------------------------------
-// ONE launch, a workgroup per output column j (until round 3: T2 = Nh . Cb and Cb^T . T2 as two launches, 5.9 + 5.5 us of pure
-// latency): column j of T2 needs all of Nh and column j of Cb only, column j of the result all of Cb and that column of T2 --
-// no workgroup waits for another.  Everything a thread will read from memory is requested before the first barrier (the operands of
-// the second product do not depend on the first), the sums are split in a fixed way: the same bits on every rank.
-constexpr int kNormH = 64, kNormX = 2 * kNormH, kNormM = 128;
-__global__ __launch_bounds__(kBT) void big_norm_kernel(NarrowParams p, const float *__restrict__ Cb, const int *__restrict__ m_dev) {
-  __shared__ double sN[kNormH * kNormH];
-  __shared__ float sC[kNormX];
-  __shared__ double sT[2][kNormX];
-  __shared__ double sO[4][kNormM];
-  const int D = kD, h = p.h, m = m_dev[0], hD = h * D, j = blockIdx.x, t = threadIdx.x;
-  if (j >= m) return;                                  // (the grid is sized for the cap; adaptive truncation may keep fewer)
-  const int q = t >> 6, lane = t & 63, XQ = (hD + 3) / 4;
-  float c2[kNormX / 4];                                // rows x = q XQ + u of column `lane` of Cb
-#pragma unroll
-  for (int u = 0; u < kNormX / 4; ++u) {
-    const int x = q * XQ + u;
-    c2[u] = (u < XQ && x < hD && lane < m) ? Cb[(size_t)x * m + lane] : 0.f;
-  }
-  if (t < hD) sC[t] = Cb[(size_t)t * m + j];
-  if (p.Nh) for (int e = t; e < h * h; e += kBT) sN[e] = p.Nh[e];
-  __syncthreads();
-  {                                                    // T2[x][j], x = (a', d): two halves of the sum over a
-    const int x = t & (kNormX - 1), half = t >> 7;
-    if (x < hD) {
-      const int ap = x / D, d = x - ap * D;
-      double acc = 0.0;
-      if (p.Nh) {
-        const int H2 = (h + 1) / 2, a1 = min(h, (half + 1) * H2);
-        for (int a = half * H2; a < a1; ++a) acc = fma(sN[ap * h + a], (double)sC[a * D + d], acc);
-      } else if (half == 0) acc = (double)sC[x];
-      sT[half][x] = acc;
-    }
-  }
-  __syncthreads();
-  if (lane < m) {                                      // out[i][j], i = lane: four quarters of the sum over x
+// 16 lanes share one output element and split its inner sum (the outputs alone are too few to fill the chip);
+// the partial sums meet by xor shuffles inside the 16-lane group, in a fixed order
+__global__ __launch_bounds__(kBT) void big_norm_T_kernel(NarrowParams p, const float *__restrict__ Cb, double *__restrict__ T2,
+                                                        const int *__restrict__ m_dev) {
+  const int D = kD, h = p.h, m = m_dev[0], DM = D * m;
+  const int sub = threadIdx.x & 15;
+  for (int e = (blockIdx.x * kBT + threadIdx.x) >> 4; e < h * DM; e += (gridDim.x * kBT) >> 4) {
+    const int j = e % DM, i = e / DM;
     double acc = 0.0;
-#pragma unroll
-    for (int u = 0; u < kNormX / 4; ++u) {
-      const int x = q * XQ + u;
-      if (u < XQ && x < hD) acc = fma((double)c2[u], sT[0][x] + sT[1][x], acc);
-    }
-    sO[q][lane] = acc;
+    if (p.Nh) { for (int kk = sub; kk < h; kk += 16) acc += p.Nh[i * h + kk] * (double)Cb[(size_t)kk * DM + j]; }
+    else if (sub == 0) acc = (double)Cb[e];
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (sub == 0) T2[e] = acc;
   }
-  for (int i = lane + 64; i < m; i += 64) {            // (kept ranks beyond 64: not on the training path)
-    double acc = 0.0;
-    for (int u = 0; u < XQ; ++u) {
-      const int x = q * XQ + u;
-      if (x < hD) acc = fma((double)Cb[(size_t)x * m + i], sT[0][x] + sT[1][x], acc);
-    }
-    sO[q][i] = acc;
-  }
-  __syncthreads();
-  for (int i = t; i < m; i += kBT) p.Nh_new[(size_t)i * m + j] = (sO[0][i] + sO[1][i]) + (sO[2][i] + sO[3][i]);
 }
+__global__ __launch_bounds__(kBT) void big_norm_out_kernel(NarrowParams p, const float *__restrict__ Cb, const double *__restrict__ T2,
+                                                          const int *__restrict__ m_dev) {
+  const int D = kD, h = p.h, m = m_dev[0];
+  const int sub = threadIdx.x & 15;
+  for (int e = (blockIdx.x * kBT + threadIdx.x) >> 4; e < m * m; e += (gridDim.x * kBT) >> 4) {
+    const int j = e % m, i = e / m;
+    double acc = 0.0;
+    for (int kk = sub; kk < h * D; kk += 16) acc += (double)Cb[(size_t)kk * m + i] * T2[(size_t)kk * m + j];
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (sub == 0) p.Nh_new[e] = acc;
+  }
+}
+// (one launch with a workgroup per output column was tried in round 3 -- 14 us against 5.9 + 5.5 for these two: removed)
 
 }  // namespace
 
@@ -742,38 +835,51 @@ static bool big_launch_done(const char *name, bool check, dim3 grid, dim3 block,
 //       P'_k[(h', d')][s] = E_k[h'][s] x_k[s][d']
 //     64 samples per workgroup, the core in LDS (every lane of a wave reads the same element: a broadcast), four groups of
 //     bond indices; plain FMAs: 25 MFLOP, a few microseconds beside a 170 us Jacobi kernel.
-__global__ __launch_bounds__(256) void big_ext_kernel(const float *__restrict__ Eprev, const float *__restrict__ x_km1,
-                                                     const float *__restrict__ x_k, CoreView A, int b_pad,
-                                                     float *__restrict__ Ecur, float *__restrict__ Pk) {
-  extern __shared__ __attribute__((aligned(16))) float sAext[];          // [(h, d)][h' padded to a multiple of 4]
-  const int hp = A.n_in, h = A.n_out, nI = hp * kD, HS = (h + 3) & ~3;
+struct BigExtArgs { const float *Eprev, *x_km1, *x_k; CoreView A; int b_pad; float *Ecur, *Pk; };
+//     (`bx`: which 64 samples, `by`: which sixteen bond indices; the loads of eight environment rows are in flight together -- with one
+//      per loop trip the kernel was one L2 latency per row: 15 us at C5)
+__device__ inline void big_ext_body(const BigExtArgs &a, float *sAext, int bx, int by) {
+  const CoreView &A = a.A;
+  const int hp = A.n_in, h = A.n_out, nI = hp * kD, HS = (h + 3) & ~3, b_pad = a.b_pad;
   for (int e = threadIdx.x; e < nI * HS; e += 256) {
     const int i = e / HS, o = e - i * HS;
     sAext[e] = o < h ? A.base[(size_t)(i >> 1) * A.s_in + (i & 1) * A.s_d + (size_t)o * A.s_out] : 0.f;
   }
   __syncthreads();
   // 64 samples x 16 bond indices per workgroup: a lane owns one sample and four consecutive h' (one 16-byte LDS read per core row)
-  const int s = blockIdx.x * 64 + (threadIdx.x & 63), o = blockIdx.y * 16 + 4 * (threadIdx.x >> 6);
+  const int s = bx * 64 + (threadIdx.x & 63), o = by * 16 + 4 * (threadIdx.x >> 6);
   if (o >= h) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float xm0 = x_km1[(size_t)s * kD], xm1 = x_km1[(size_t)s * kD + 1];
-  for (int hh = 0; hh < hp; ++hh) {
-    const float e = Eprev[(size_t)hh * b_pad + s];
-    const float e0 = e * xm0, e1 = e * xm1;
-    const float4 a0 = *reinterpret_cast<const float4 *>(sAext + (size_t)(2 * hh) * HS + o);
-    const float4 a1 = *reinterpret_cast<const float4 *>(sAext + (size_t)(2 * hh + 1) * HS + o);
-    acc.x = fmaf(e1, a1.x, fmaf(e0, a0.x, acc.x)); acc.y = fmaf(e1, a1.y, fmaf(e0, a0.y, acc.y));
-    acc.z = fmaf(e1, a1.z, fmaf(e0, a0.z, acc.z)); acc.w = fmaf(e1, a1.w, fmaf(e0, a0.w, acc.w));
+  const float xm0 = a.x_km1[(size_t)s * kD], xm1 = a.x_km1[(size_t)s * kD + 1];
+  const float x0 = a.x_k[(size_t)s * kD], x1 = a.x_k[(size_t)s * kD + 1];
+  for (int h0 = 0; h0 < hp; h0 += 8) {
+    float ev[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ev[u] = a.Eprev[(size_t)min(h0 + u, hp - 1) * b_pad + s];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int hh = h0 + u;
+      if (hh < hp) {
+        const float e0 = ev[u] * xm0, e1 = ev[u] * xm1;
+        const float4 a0 = *reinterpret_cast<const float4 *>(sAext + (size_t)(2 * hh) * HS + o);
+        const float4 a1 = *reinterpret_cast<const float4 *>(sAext + (size_t)(2 * hh + 1) * HS + o);
+        acc.x = fmaf(e1, a1.x, fmaf(e0, a0.x, acc.x)); acc.y = fmaf(e1, a1.y, fmaf(e0, a0.y, acc.y));
+        acc.z = fmaf(e1, a1.z, fmaf(e0, a0.z, acc.z)); acc.w = fmaf(e1, a1.w, fmaf(e0, a0.w, acc.w));
+      }
+    }
   }
-  const float x0 = x_k[(size_t)s * kD], x1 = x_k[(size_t)s * kD + 1];
   const float v[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
   for (int u = 0; u < 4; ++u)
     if (o + u < h) {
-      Ecur[(size_t)(o + u) * b_pad + s] = v[u];
-      Pk[(size_t)(2 * (o + u)) * b_pad + s] = v[u] * x0;
-      Pk[(size_t)(2 * (o + u) + 1) * b_pad + s] = v[u] * x1;
+      a.Ecur[(size_t)(o + u) * b_pad + s] = v[u];
+      a.Pk[(size_t)(2 * (o + u)) * b_pad + s] = v[u] * x0;
+      a.Pk[(size_t)(2 * (o + u) + 1) * b_pad + s] = v[u] * x1;
     }
+}
+__global__ __launch_bounds__(256) void big_ext_kernel(BigExtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sAext[];          // [(h, d)][h' padded to a multiple of 4]
+  big_ext_body(a, sAext, blockIdx.x, blockIdx.y);
 }
 
 // (2) The raw gradient of step k+1 from the reduced pre-gradient and the behind core the SVD of step k has just left:
@@ -823,18 +929,109 @@ __global__ __launch_bounds__(64) void big_contract_kernel(const float *__restric
   extern __shared__ __attribute__((aligned(16))) float sAc[];             // [(h, d)][8]
   big_contract_body(Z, A, ncols, red, sAc, blockIdx.x, blockIdx.y, blockIdx.x == 0 && blockIdx.y == 0);
 }
-// The contraction and the merged tensor of the same step need nothing from each other: one launch, the contraction's workgroups
-// first (theirs is the longer latency chain), four column chunks each.
-__global__ __launch_bounds__(kBT) void big_front_kernel(NarrowParams p, float *__restrict__ Bf, const float *__restrict__ Z, CoreView A,
-                                                       int ncols, float *__restrict__ red, int ncx, int ncontract) {
+// ---- hand-offs between the context's stream and the side stream without events (round 3) -----------------------------------------
+// A cross-queue event dependency costs 6-7 us on the stream that records or waits even when it is already satisfied, and 12-14 us
+// from the producer's end to the consumer's start (tools/c5_gaps.py).  Instead: the producer's stream runs a one-thread kernel that
+// stores a sequence number (big_signal_kernel: everything before it in its stream is complete and visible at agent scope), and the
+// consumer either polls that word from the workgroups that need the data (big_front_kernel) or runs a one-wave kernel in front of them
+// that does (big_gate_kernel).  A waiting kernel is always enqueued AFTER the kernels it waits for, the waits are bounded, and a
+// time-out sets a status bit the host reports (TNML_ERR_STATE).
+__global__ void big_signal_kernel(unsigned *flag, unsigned value) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline bool big_flag_reached(const unsigned *flag, unsigned want) {
+  return (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;      // (sequence numbers wrap)
+}
+__device__ inline void big_spin(const unsigned *flag, unsigned want, int *status, int bit) {
+  for (int spin = 0; spin < (1 << 22); ++spin) {
+    if (big_flag_reached(flag, want)) return;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  atomicOr(status, bit);
+}
+__global__ void big_gate_kernel(const unsigned *flag, unsigned want, int *status) {
+  if (threadIdx.x == 0) big_spin(flag, want, status, 32);
+}
+// inside a workgroup: thread 0 waits, everybody leaves with what was written before the signal visible (agent-scope acquire: the
+// L2 of this XCD may hold lines of the same buffer from an earlier step)
+// (acquire = false: the caller only must not WRITE before the signal -- nothing it reads was written by the other stream)
+__device__ inline void big_poll(const unsigned *flag, unsigned want, int *status, bool acquire) {
+  if (threadIdx.x == 0) big_spin(flag, want, status, 64);
+  __syncthreads();
+  if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// The contraction and the two small products of the L2 term need nothing from each other: one launch, the contraction's workgroups
+// first (theirs is the longer latency chain), four column chunks each; then NL = Nh^T . lab and PR = pl . Ng (big_merge_wd_kernel).
+__device__ inline void big_nlpr_body(const NarrowParams &p, double *__restrict__ NL, double *__restrict__ PR, int blk, int nblk) {
+  const int D = kD, h = p.h, g = p.g, sb = p.s, L = p.L;
+  const int nNL = h * D * sb * L, nPR = sb * D * g;
+  for (int o = blk * kBT + threadIdx.x; o < nNL + nPR; o += nblk * kBT) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (o < nNL) {                                     // NL[h', dk, s, l] = sum_a Nh[a, h'] lab(a, dk, s, l)
+      const int l = o % L;
+      int q = o / L;
+      const int s_ = q % sb; q /= sb;
+      const int dk = q % D, hq = q / D;
+      const float *la = p.lab.base + dk * p.lab.s_d + s_ * p.lab.s_out + l;
+      if (!p.Nh) { NL[o] = (double)la[hq * p.lab.s_in]; continue; }
+      const double *nh = p.Nh + hq;
+      int a = 0;
+      for (; a + 8 <= h; a += 8) {
+        double nv[8]; float lv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { nv[u] = nh[(size_t)(a + u) * h]; lv[u] = la[(a + u) * p.lab.s_in]; }
+        a0 = fma(nv[0], (double)lv[0], a0); a1 = fma(nv[1], (double)lv[1], a1); a2 = fma(nv[2], (double)lv[2], a2); a3 = fma(nv[3], (double)lv[3], a3);
+        a0 = fma(nv[4], (double)lv[4], a0); a1 = fma(nv[5], (double)lv[5], a1); a2 = fma(nv[6], (double)lv[6], a2); a3 = fma(nv[7], (double)lv[7], a3);
+      }
+      for (; a < h; ++a) a0 = fma(nh[(size_t)a * h], (double)la[a * p.lab.s_in], a0);
+      NL[o] = (a0 + a1) + (a2 + a3);
+    } else {                                           // PR[s, dk1, f] = sum_c pl(s, dk1, c) Ng[c, f]
+      const int oo = o - nNL;
+      const int f_ = oo % g;
+      int q = oo / g;
+      const int dk1 = q % D, s_ = q / D;
+      const float *pl = p.pl.base + s_ * p.pl.s_in + dk1 * p.pl.s_d;
+      if (!p.Ng) { PR[oo] = (double)pl[f_ * p.pl.s_out]; continue; }
+      const double *ng = p.Ng + f_;
+      int c = 0;
+      for (; c + 8 <= g; c += 8) {
+        double nv[8]; float pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { nv[u] = ng[(size_t)(c + u) * g]; pv[u] = pl[(c + u) * p.pl.s_out]; }
+        a0 = fma((double)pv[0], nv[0], a0); a1 = fma((double)pv[1], nv[1], a1); a2 = fma((double)pv[2], nv[2], a2); a3 = fma((double)pv[3], nv[3], a3);
+        a0 = fma((double)pv[4], nv[4], a0); a1 = fma((double)pv[5], nv[5], a1); a2 = fma((double)pv[6], nv[6], a2); a3 = fma((double)pv[7], nv[7], a3);
+      }
+      for (; c < g; ++c) a0 = fma((double)pl[c * p.pl.s_out], ng[(size_t)c * g], a0);
+      PR[oo] = (a0 + a1) + (a2 + a3);
+    }
+  }
+}
+__global__ __launch_bounds__(kBT) void big_front_kernel(NarrowParams p, double *__restrict__ NL, double *__restrict__ PR,
+                                                       const float *__restrict__ Z, CoreView A, int ncols, float *__restrict__ red,
+                                                       int ncx, int ncontract, BigExtArgs ext, int next_x, int next,
+                                                       const unsigned *poll_flag, unsigned poll_want, int ext_acquire) {
   extern __shared__ __attribute__((aligned(16))) float sAc[];
   const int bid = blockIdx.x;
+  // Z, and the buffers the extension rewrites, belong to the side stream until its chain of the previous step has signalled.  The
+  // contraction READS what that stream wrote (acquire: 56 workgroups); the extension reads it only behind the first pipelined step of
+  // a sweep, whose own extension ran over there (an acquire in each of its 316 workgroups empties this XCD's L2 as often: +9 us).
+  if (poll_flag && bid < ncontract + next) big_poll(poll_flag, poll_want, p.status, bid < ncontract || ext_acquire != 0);
   if (bid < ncontract) {
     const int bx = bid % ncx, by = bid / ncx;
     big_contract_body(Z, A, ncols, red, sAc, bx * (kBT / 64) + (int)(threadIdx.x >> 6), by, bid == 0);
+  } else if (bid < ncontract + next) {
+    // behind environment E_k and P'_k for the batch kernel "of step k+1" on the side stream: they need only what step k-1 left, and
+    // the side stream's chain (as long as the Jacobi kernel) is the shorter for not carrying them
+    const int b = bid - ncontract;
+    big_ext_body(ext, sAc, b % next_x, b / next_x);
   } else {
-    big_merge_body(p, Bf, bid - ncontract, (int)gridDim.x - ncontract);
+    big_nlpr_body(p, NL, PR, bid - ncontract - next, (int)gridDim.x - ncontract - next);
   }
+}
+
+__global__ __launch_bounds__(kBT) void big_nlpr_kernel(NarrowParams p, double *__restrict__ NL, double *__restrict__ PR) {
+  big_nlpr_body(p, NL, PR, blockIdx.x, gridDim.x);
 }
 
 bool launch_big_ext(const float *Eprev, const float *x_km1, const float *x_k, const CoreView &A, int b_pad, float *Ecur, float *Pk,
@@ -844,7 +1041,16 @@ bool launch_big_ext(const float *Eprev, const float *x_km1, const float *x_k, co
     snprintf(g_big_err, sizeof g_big_err, "big_ext_kernel: core %d x %d x %d, b_pad %d", A.n_in, kD, A.n_out, b_pad);
     return false;
   }
-  hipLaunchKernelGGL(big_ext_kernel, dim3(b_pad / 64, (A.n_out + 15) / 16), dim3(256), lds, st, Eprev, x_km1, x_k, A, b_pad, Ecur, Pk);
+  BigExtArgs a{Eprev, x_km1, x_k, A, b_pad, Ecur, Pk};
+  hipLaunchKernelGGL(big_ext_kernel, dim3(b_pad / 64, (A.n_out + 15) / 16), dim3(256), lds, st, a);
+  return true;
+}
+bool launch_big_signal(unsigned *flag, unsigned value, hipStream_t st) {
+  hipLaunchKernelGGL(big_signal_kernel, dim3(1), dim3(64), 0, st, flag, value);
+  return true;
+}
+bool launch_big_gate(const unsigned *flag, unsigned want, int *status, hipStream_t st) {
+  hipLaunchKernelGGL(big_gate_kernel, dim3(1), dim3(64), 0, st, flag, want, status);
   return true;
 }
 bool launch_big_contract(const float *Zred, const CoreView &A, int ncols, float *red, hipStream_t st) {
@@ -861,7 +1067,7 @@ bool launch_big_contract(const float *Zred, const CoreView &A, int ncols, float 
 // produces: the merged tensor and T = Nh^T . B.  The host may enqueue it on a second stream beside the batch kernel
 // (`prep_only`), and then asks the chain proper to skip it (`skip_prep`).
 bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check, bool prep_only, bool skip_prep,
-                       hipEvent_t after_update, const BigFront *front) {
+                       hipEvent_t after_update, const BigFront *front, unsigned *sig_flag, unsigned sig_val) {
   const int D = kD, Bs = p.bsize;
   const int r = D * p.h, c = D * p.g * p.L;
   const bool short_rows = r <= c;
@@ -873,6 +1079,7 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   }
   const int nbe = std::min((Bs + kBT - 1) / kBT, 2048);          // one element per thread
   const int nb = std::min((Bs + kBT - 1) / kBT, kBigParts);      // kernels that leave block partials
+  const int nb4 = std::min((Bs + kBT / 4 - 1) / (kBT / 4), kBigParts);   // ... at four lanes per element
   const float *Bf = p.Bdirect;
 #define BIG(kern, grid, block, lds, ...)                                          \
   do {                                                                            \
@@ -882,11 +1089,21 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
     hipLaunchKernelGGL(kern, g_, b_, l_, st, __VA_ARGS__);                        \
     if (!big_launch_done(#kern, check, g_, b_, l_)) return false;                 \
   } while (0)
-  if (front && (Bf || skip_prep)) {            // no merged tensor to form beside it: the contraction alone
+  // Steps that form their merged tensor here, on this stream, take it and the L2 term straight from the two cores ("factored");
+  // a given merged tensor and a preparation that ran ahead on the side stream keep T = Nh^T . B.
+  const bool factored = !Bf && !skip_prep && !prep_only;
+  double *ws = p.dbg;                          // the capture block doubles as the workspace of this path
+  double *NL = s.T, *PR = s.T + (size_t)p.h * D * p.s * p.L;
+  if (front && !factored) {                    // no products to form beside it: the contraction alone
+    if (front->poll_flag && (!front->wait_ev || hipStreamWaitEvent(st, front->wait_ev, 0) != hipSuccess)) {
+      snprintf(g_big_err, sizeof g_big_err, "large-tensor path: cannot join the side stream in front of the contraction");
+      return false;
+    }
     if (!launch_big_contract(front->Z, front->A, front->ncols, front->red, st)) return false;
     front = nullptr;
   }
-  if (!Bf) {
+  if (factored) {
+    const int nlpr = p.l2_flag ? std::min((p.h * D * p.s * p.L + p.s * D * p.g + kBT - 1) / kBT, 2048) : 0;
     if (front) {
       const int ncx = (front->ncols + kBT - 1) / kBT, ncontract = ncx * ((front->A.n_out + 7) / 8);
       const size_t lds = (size_t)front->A.n_in * kD * 8 * sizeof(float);
@@ -894,23 +1111,42 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
         snprintf(g_big_err, sizeof g_big_err, "big_front_kernel: core %d x %d x %d, %d columns", front->A.n_in, kD, front->A.n_out, front->ncols);
         return false;
       }
-      BIG(big_front_kernel, dim3(ncontract + nbe), dim3(kBT), lds, p, s.Bf, front->Z, front->A, front->ncols, front->red, ncx, ncontract);
-    } else if (!skip_prep) BIG(big_merge_kernel, dim3(nbe), dim3(kBT), 0, p, s.Bf);
-    Bf = s.Bf;
+      BigExtArgs ext{};
+      int next_x = 0, next = 0;
+      size_t lds_f = lds;
+      if (front->ext_Ecur) {
+        const CoreView &EA = front->ext_A;
+        const size_t lds_e = (size_t)EA.n_in * kD * ((EA.n_out + 3) & ~3) * sizeof(float);
+        if (EA.n_out < 1 || lds_e > 160 * 1024 || front->b_pad % 64) {
+          snprintf(g_big_err, sizeof g_big_err, "big_front_kernel: extension core %d x %d x %d, b_pad %d", EA.n_in, kD, EA.n_out, front->b_pad);
+          return false;
+        }
+        ext = BigExtArgs{front->ext_Eprev, front->ext_x_km1, front->ext_x_k, EA, front->b_pad, front->ext_Ecur, front->ext_Pk};
+        next_x = front->b_pad / 64; next = next_x * ((EA.n_out + 15) / 16);
+        lds_f = std::max(lds, lds_e);
+      }
+      BIG(big_front_kernel, dim3(ncontract + next + nlpr), dim3(kBT), lds_f, p, NL, PR, front->Z, front->A, front->ncols, front->red, ncx,
+          ncontract, ext, next_x, next, (const unsigned *)front->poll_flag, front->poll_want, front->ext_acquire ? 1 : 0);
+    } else if (nlpr) BIG(big_nlpr_kernel, dim3(nlpr), dim3(kBT), 0, p, NL, PR);
+    BIG(big_merge_wd_kernel, dim3(nb4), dim3(kBT), 0, p, s.Bf, (const double *)NL, (const double *)PR, ws, s.part);
+  } else {
+    if (!Bf) {
+      if (!skip_prep) BIG(big_merge_kernel, dim3(nbe), dim3(kBT), 0, p, s.Bf);
+      Bf = s.Bf;
+    }
+    if (p.l2_flag && !skip_prep) BIG(big_l2_T_kernel, dim3(nbe), dim3(kBT), 0, p, Bf, s.T);
+    if (prep_only) return true;
+    BIG(big_wd_kernel, dim3(nb), dim3(kBT), 0, p, Bf, (const double *)s.T, ws, s.part);
   }
-  double *ws = p.dbg;                          // the capture block doubles as the workspace of this path
-  if (p.l2_flag && !skip_prep) BIG(big_l2_T_kernel, dim3(nbe), dim3(kBT), 0, p, Bf, s.T);
-  if (prep_only) return true;
-  BIG(big_wd_kernel, dim3(nb), dim3(kBT), 0, p, Bf, (const double *)s.T, ws, s.part);
-  BIG(big_update_kernel, dim3(nb), dim3(kBT), 0, p, ws, (const double *)s.part, nb);
+  BIG(big_update_kernel, dim3(nb), dim3(kBT), 0, p, ws, (const double *)s.part, factored ? nb4 : nb);
   // B_new is complete: the batch kernel of the NEXT step may start beside the SVD of this one (pipelined large-tensor step)
-  if (after_update && hipEventRecord(after_update, st) != hipSuccess) {
+  if (!sig_flag && after_update && hipEventRecord(after_update, st) != hipSuccess) {
     snprintf(g_big_err, sizeof g_big_err, "hipEventRecord behind big_update_kernel failed");
     return false;
   }
   if (p.stop_after_update) return true;
   const int nt = (n + 15) / 16;
-  BIG(big_gram_kernel, dim3(nt, nt, kGramKS), dim3(256), 0, (const float *)p.Bnew, n, len, si, sx, s.gram);
+  BIG(big_gram_kernel, dim3(nt, nt, kGramKS), dim3(256), 0, (const float *)p.Bnew, n, len, si, sx, s.gram, sig_flag, sig_val);
   BigJacobiArgs a{};
   a.G = s.gram; a.n = n; a.m = p.m; a.stop2 = p.svd_stop2; a.rotlog = s.rotlog; a.lam = s.lam; a.info = s.info;
   a.counters = p.counters; a.status = p.status;
@@ -923,11 +1159,10 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   BIG(big_cores_kernel, dim3(std::min(((n + len) * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, p, (const double *)s.lam,
       (const int *)s.info, (const double *)s.VW, s.Cb);
   if (p.Nh_new) {
-    if (p.h > kNormH || p.m > kNormM) {
-      snprintf(g_big_err, sizeof g_big_err, "big_norm_kernel: behind bond %d, kept rank %d", p.h, p.m);
-      return false;
-    }
-    BIG(big_norm_kernel, dim3(p.m), dim3(kBT), 0, p, (const float *)s.Cb, (const int *)(s.info + 3));
+    const int nb2 = std::min((16 * p.h * D * p.m + kBT - 1) / kBT, 1024);
+    BIG(big_norm_T_kernel, dim3(nb2), dim3(kBT), 0, p, (const float *)s.Cb, s.T2, (const int *)(s.info + 3));
+    BIG(big_norm_out_kernel, dim3(std::min((16 * p.m * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, p, (const float *)s.Cb,
+        (const double *)s.T2, (const int *)(s.info + 3));
   }
 #undef BIG
   return true;

@@ -95,6 +95,16 @@ static void check_wide(const WideParams &p, int nblk, bool f_only = false) {
     need(p.slabs, (size_t)nblk * p.slab_stride * 4, "WideParams.slabs");
   }
 }
+struct BigExtArgs { const float *Eprev, *x_km1, *x_k; CoreView A; int b_pad; float *Ecur, *Pk; };     // kernels_big.hip
+static void check_big_ext(const BigExtArgs &a, size_t shm) {
+  const CoreView &A = a.A;
+  const size_t bp = (size_t)a.b_pad;
+  need(a.Eprev, (size_t)A.n_in * bp * 4, "big_ext: E_{k-1}");
+  need(a.x_km1, bp * kD * 4, "big_ext: x_{k-1}"); need(a.x_k, bp * kD * 4, "big_ext: x_k");
+  need(A.base, view_extent(A, 1) * 4, "big_ext: core");
+  need(a.Ecur, (size_t)A.n_out * bp * 4, "big_ext: E_k"); need(a.Pk, (size_t)kD * A.n_out * bp * 4, "big_ext: P'_k");
+  if (shm < (size_t)A.n_in * kD * ((A.n_out + 3) & ~3) * 4) die("big_ext: %zu bytes of LDS for a %d x %d x %d core", shm, A.n_in, kD, A.n_out);
+}
 static void check_narrow(const NarrowParams &p) {
   scan(&p, sizeof p, "NarrowParams");
   if (p.bsize != p.h * kD * kD * p.g * p.L) die("NarrowParams.bsize %d != h D D g L (%d %d %d)", p.bsize, p.h, p.g, p.L);
@@ -226,27 +236,41 @@ hipError_t hipLaunchKernel(const void *fn, dim3 g, dim3 b, void **args, size_t s
   } else if (has("env_chain_kernel")) {
     check_chain(*(const ChainSite **)args[0], *(int *)args[1], *(const float **)args[2], *(const float **)args[3], *(const float **)args[4],
                 has("<true>") ? nullptr : *(float **)args[5], *(float **)args[6], *(int *)args[8], *(int *)args[9]);
-  } else if (has("big_wd_kernel")) {       // (NarrowParams, merged tensor, Nh^T.B, workspace, block partials): the large-tensor chain's entry
+  } else if (has("big_merge_wd_kernel")) { // (NarrowParams, merged tensor out, NL, PR, workspace, block partials): the factored chain's entry
+    const NarrowParams &n = *(const NarrowParams *)args[0];
+    check_narrow(n);
+    need(*(float **)args[1], (size_t)n.bsize * 4, "large-tensor path: merged tensor");
+    if (n.l2_flag) {
+      need(*(const double **)args[2], (size_t)n.h * kD * n.s * n.L * 8, "large-tensor path: NL");
+      need(*(const double **)args[3], (size_t)n.s * kD * n.g * 8, "large-tensor path: PR");
+    }
+    if (g.x > (unsigned)kBigParts) die("big_merge_wd_kernel: %u blocks leave partials, room for %d", g.x, kBigParts);
+    need(*(double **)args[5], (size_t)g.x * 3 * 8, "large-tensor path: block partials");
+  } else if (has("big_wd_kernel")) {       // (NarrowParams, merged tensor, Nh^T.B, workspace, block partials): the classic chain's entry
     const NarrowParams &n = *(const NarrowParams *)args[0];
     check_narrow(n);
     need(*(const float **)args[1], (size_t)n.bsize * 4, "large-tensor path: merged tensor");
     if (n.l2_flag) need(*(const double **)args[2], (size_t)n.bsize * 8, "large-tensor path: Nh^T.B");
-    need(*(double **)args[4], (size_t)kBigParts * 3 * 8, "large-tensor path: block partials");
+    if (g.x > (unsigned)kBigParts) die("big_wd_kernel: %u blocks leave partials, room for %d", g.x, kBigParts);
+    need(*(double **)args[4], (size_t)g.x * 3 * 8, "large-tensor path: block partials");
+  } else if (has("big_nlpr_kernel")) {     // (NarrowParams, NL, PR)
+    const NarrowParams &n = *(const NarrowParams *)args[0];
+    check_narrow(n);
+    need(*(double **)args[1], (size_t)n.h * kD * n.s * n.L * 8, "big_nlpr: NL");
+    need(*(double **)args[2], (size_t)n.s * kD * n.g * 8, "big_nlpr: PR");
+    if (*(double **)args[2] < *(double **)args[1] + (size_t)n.h * kD * n.s * n.L) die("big_nlpr: PR overlaps NL");
   } else if (has("big_gram_kernel")) {     // (B_new, n, len, si, sx, gram)
     const int n = *(int *)args[1], len = *(int *)args[2];
     need(*(const float **)args[0], (size_t)n * len * 4, "large-tensor path: B_new");
     need(*(double **)args[5], (size_t)8 * kBigMaxN * kBigMaxN * 8, "large-tensor path: partial Gram matrices");
     if (n > kBigMaxN || (n & 1)) die("big_gram_kernel: short side %d", n);
-  } else if (has("big_ext_kernel")) {      // (E_{k-1}, x_{k-1}, x_k, core view, b_pad, E_k, P'_k)
-    const CoreView &A = *(const CoreView *)args[3];
-    const size_t bp = *(int *)args[4];
-    if (g.x * 64 != bp) die("big_ext_kernel: grid %u x 64 samples != b_pad %zu", g.x, bp);
-    need(*(const float **)args[0], (size_t)A.n_in * bp * 4, "big_ext: E_{k-1}");
-    need(*(const float **)args[1], bp * kD * 4, "big_ext: x_{k-1}"); need(*(const float **)args[2], bp * kD * 4, "big_ext: x_k");
-    need(A.base, view_extent(A, 1) * 4, "big_ext: core");
-    need(*(float **)args[5], (size_t)A.n_out * bp * 4, "big_ext: E_k"); need(*(float **)args[6], (size_t)kD * A.n_out * bp * 4, "big_ext: P'_k");
-    if (shm < (size_t)A.n_in * kD * ((A.n_out + 3) & ~3) * 4) die("big_ext_kernel: %zu bytes of LDS for a %d x %d x %d core", shm, A.n_in, kD, A.n_out);
-    if ((int)g.y * 16 < A.n_out) die("big_ext_kernel: %u workgroup rows of 16 for %d bond indices", g.y, A.n_out);
+    if ((int)g.x * 16 < n || (int)g.y * 16 < n) die("big_gram_kernel: grid (%u, %u) of 16 x 16 tiles for n = %d", g.x, g.y, n);
+    if (*(unsigned **)args[6]) need(*(unsigned **)args[6], 4, "big_gram: flag word of the side stream");
+  } else if (has("big_ext_kernel")) {      // (BigExtArgs: E_{k-1}, x_{k-1}, x_k, core view, b_pad, E_k, P'_k)
+    check_big_ext(*(const BigExtArgs *)args[0], shm);
+    const BigExtArgs &a = *(const BigExtArgs *)args[0];
+    if ((int)g.x * 64 != a.b_pad) die("big_ext_kernel: grid %u x 64 samples != b_pad %d", g.x, a.b_pad);
+    if ((int)g.y * 16 < a.A.n_out) die("big_ext_kernel: %u workgroup rows of 16 for %d bond indices", g.y, a.A.n_out);
   } else if (has("big_contract_kernel")) { // (Z, core view, ncols, red)
     const CoreView &A = *(const CoreView *)args[1];
     const size_t nc = *(int *)args[2];
@@ -255,28 +279,36 @@ hipError_t hipLaunchKernel(const void *fn, dim3 g, dim3 b, void **args, size_t s
     need(*(float **)args[3], ((size_t)A.n_out * nc + kMetricSlots) * 4, "big_contract: raw gradient");
     if (shm < (size_t)A.n_in * kD * 8 * 4) die("big_contract_kernel: %zu bytes of LDS", shm);
     if ((size_t)g.x * 64 < nc || (int)g.y * 8 < A.n_out) die("big_contract_kernel: grid (%u, %u) for %zu columns, %d rows", g.x, g.y, nc, A.n_out);
-  } else if (has("big_front_kernel")) {    // (NarrowParams, merged tensor out, Z, core view, ncols, red, ncx, ncontract)
+  } else if (has("big_front_kernel")) {    // (NarrowParams, NL, PR, Z, core view, ncols, red, ncx, ncontract)
     const NarrowParams &n = *(const NarrowParams *)args[0];
     check_narrow(n);
-    need(*(float **)args[1], (size_t)n.bsize * 4, "big_front: merged tensor");
-    const CoreView &A = *(const CoreView *)args[3];
-    const size_t nc = *(int *)args[4];
-    const int ncx = *(int *)args[6], ncontract = *(int *)args[7];
-    need(*(const float **)args[2], ((size_t)A.n_in * kD * nc + kMetricSlots) * 4, "big_front: Z");
+    const CoreView &A = *(const CoreView *)args[4];
+    const size_t nc = *(int *)args[5];
+    const int ncx = *(int *)args[7], ncontract = *(int *)args[8];
+    if (n.l2_flag) {
+      need(*(double **)args[1], (size_t)n.h * kD * n.s * n.L * 8, "big_front: NL");
+      need(*(double **)args[2], (size_t)n.s * kD * n.g * 8, "big_front: PR");
+      if (*(double **)args[2] < *(double **)args[1] + (size_t)n.h * kD * n.s * n.L) die("big_front: PR overlaps NL");
+    }
+    need(*(const float **)args[3], ((size_t)A.n_in * kD * nc + kMetricSlots) * 4, "big_front: Z");
     need(A.base, view_extent(A, 1) * 4, "big_front: core");
-    need(*(float **)args[5], ((size_t)A.n_out * nc + kMetricSlots) * 4, "big_front: raw gradient");
+    need(*(float **)args[6], ((size_t)A.n_out * nc + kMetricSlots) * 4, "big_front: raw gradient");
     if (shm < (size_t)A.n_in * kD * 8 * 4) die("big_front_kernel: %zu bytes of LDS", shm);
-    if ((size_t)ncx * 256 < nc || ncontract != ncx * ((A.n_out + 7) / 8) || (int)g.x <= ncontract)
+    if ((size_t)ncx * 256 < nc || ncontract != ncx * ((A.n_out + 7) / 8) || (int)g.x < ncontract)
       die("big_front_kernel: grid %u, %d x %d contraction workgroups for %zu columns, %d rows", g.x, ncx, ncontract / (ncx ? ncx : 1), nc, A.n_out);
     if ((size_t)A.n_out * nc != (size_t)n.bsize) die("big_front_kernel: gradient %d x %zu, merged tensor %d", A.n_out, nc, n.bsize);
-  } else if (has("big_norm_kernel")) {     // (NarrowParams, behind core [rows][m], kept rank on the device)
-    const NarrowParams &n = *(const NarrowParams *)args[0];
-    if (n.h > 64 || n.m > 128) die("big_norm_kernel: behind bond %d, kept rank %d", n.h, n.m);
-    need(*(const float **)args[1], (size_t)n.h * kD * n.m * 4, "big_norm: behind core");
-    need(*(const int **)args[2], 4, "big_norm: kept rank");
-    if (n.Nh) need(n.Nh, (size_t)n.h * n.h * 8, "big_norm: Nh");
-    need(n.Nh_new, (size_t)n.m * n.m * 8, "big_norm: Nh_new");
-    if ((int)g.x < n.m) die("big_norm_kernel: %u workgroups for %d columns", g.x, n.m);
+    if (*(const unsigned **)args[12]) need(*(const unsigned **)args[12], 4, "big_front: sequence number of the side stream");
+    const BigExtArgs &ea = *(const BigExtArgs *)args[9];
+    const int next_x = *(int *)args[10], next = *(int *)args[11];
+    if (next) {
+      check_big_ext(ea, shm);
+      if (next_x * 64 != ea.b_pad || next != next_x * ((ea.A.n_out + 15) / 16)) die("big_front_kernel: %d x %d extension workgroups for b_pad %d, %d bond indices", next_x, next / (next_x ? next_x : 1), ea.b_pad, ea.A.n_out);
+    }
+    if ((int)g.x < ncontract + next + (n.l2_flag ? 1 : 0)) die("big_front_kernel: grid %u for %d + %d workgroups and the L2 products", g.x, ncontract, next);
+  } else if (has("big_signal_kernel")) {   // (flag, value)
+    need(*(unsigned **)args[0], 4, "big_signal: flag word");
+  } else if (has("big_gate_kernel")) {     // (flag, want, status)
+    need(*(const unsigned **)args[0], 4, "big_gate: flag word"); need(*(int **)args[2], 4, "big_gate: status");
   } else if (has("reduce_slabs")) {        // (slabs, nblk, slab_stride, n, red)
     const int nblk = *(int *)args[1], stride = *(int *)args[2], n = *(int *)args[3];
     if (n > stride) die("reduce_slabs: %d elements of a slab of %d", n, stride);

@@ -168,6 +168,7 @@ static void run_entry_points(int N, int M, int b, int L) {
     OK(tnml_set_narrow_path(ctx, mode == 2));
     OK(tnml_forward(ctx, nullptr));
     const int left = tnml_l_pos(ctx) == N - 1;
+    if (mode == 2) OK(tnml_update_B(ctx, nullptr, left, 1e-3f, 1e-3f, 1, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 1.f, Bn.data(), nB, met2));   // large-tensor path, factored form alone
     OK(tnml_debug_enable(ctx, 1));
     OK(tnml_sweep(ctx, left, 1, 1, 1e-3f, 1e-3f, 1, TNML_ACT_SOFTMAX, TNML_LOSS_FULL_CROSS_ENT, 0.1f, TNML_TRUNC_FIXED, met2, f.data()));
     std::vector<double> cap((size_t)4 * M * M * L + 4096);

@@ -68,6 +68,12 @@ struct tnml_ctx {
   float *bigPk = nullptr;                    // [D * Mmax][b_pad]  E_k (x) x_k, the row operand of Z_{k+1}
   hipEvent_t ev_upd_big = nullptr, ev_zbig = nullptr;
   bool zbig_pending = false;                 // stream2 holds batch work of the pipelined large-tensor step the context's stream has not joined
+  // hand-offs of that pipeline without events (kernels_big.hip, big_signal_kernel): [0] "Z of the next step is ready" (side stream ->
+  // context's stream), [1] "B_new is ready" (context's stream -> side stream); sequence numbers
+  unsigned *bigflags = nullptr;
+  unsigned zsig_seq = 0, bsig_seq = 0;
+  bool bigflags_enabled = true;
+  bool ext_on_side = false;                  // the last environment extension of the pipeline ran on the side stream
   hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
   // host bookkeeping
   std::vector<int> bond;
@@ -310,7 +316,7 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->comm) ncclCommDestroy(c->comm);
   void *ptrs[] = {c->X, c->Xstage, c->y, c->f, c->ftmp, c->ftmp2, c->Lenv, c->Renv, c->cores, c->lab[0], c->lab[1],
                   c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2,
-                  c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->zslabs, c->gslabs, c->zred, c->pipe_cnt, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2, c->big.prog};
+                  c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->zslabs, c->gslabs, c->zred, c->pipe_cnt, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2, c->big.prog, c->bigflags};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   void *pptrs[] = {c->zred2, c->Tbuf[0], c->Tbuf[1], c->TNbuf[0], c->TNbuf[1], c->prepRaw, c->Apub, c->pst_dev, c->pst_cnt, c->pst_flags};
   for (void *p : pptrs) if (p) (void)hipFree(p);
@@ -346,7 +352,8 @@ static int check_status(tnml_ctx *c) {
   HIP_TRY(hipMemcpy(&st, c->status, sizeof(int), hipMemcpyDeviceToHost));
   if (!st) return TNML_OK;
   HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
-  if (st & 28) {        // 4: helpers late, 8: B_new flag never seen, 16: the replay workgroups never saw the rotation log grow
+  if (st & 124) {       // 4: helpers late, 8: B_new flag never seen, 16: the replay workgroups never saw the rotation log grow,
+                        // 32 / 64: the side stream / the context's stream of the large-tensor pipeline never saw the other's sequence number
     HIP_TRY(hipMemset(c->sync, 0, sizeof(unsigned)));          // a late helper may have left the arrival counter mid-count
     HIP_TRY(hipMemset(c->pipe_cnt, 0, 17 * sizeof(unsigned)));
     c->Z_valid = false; c->Zbig_valid = false;
@@ -791,7 +798,7 @@ static int ensure_big(tnml_ctx *c) {
   const size_t rows_cols = (size_t)c->D * c->Mmax * (1 + c->L);
   HIP_TRY(hipMalloc(&c->big.Bf, c->bmax * sizeof(float)));
   HIP_TRY(hipMalloc(&c->big.T, c->bmax * sizeof(double)));
-  HIP_TRY(hipMalloc(&c->big.part, 3 * kBigParts * sizeof(double)));
+  HIP_TRY(hipMalloc(&c->big.part, (3 * kBigParts + 8) * sizeof(double)));      // block partials, then {step factor, the three sums}
   HIP_TRY(hipMalloc(&c->big.gram, (size_t)8 * kBigMaxN * kBigMaxN * sizeof(double)));
   HIP_TRY(hipMalloc(&c->big.rotlog, ((size_t)30 * (kBigMaxN - 1) + 2) * (kBigMaxN / 2) * sizeof(double2)));
   HIP_TRY(hipMalloc(&c->big.lam, 3 * kBigMaxN * sizeof(double)));
@@ -801,6 +808,8 @@ static int ensure_big(tnml_ctx *c) {
   HIP_TRY(hipMalloc(&c->big.T2, rows_cols * c->Mmax * sizeof(double)));
   HIP_TRY(hipMalloc(&c->big.prog, 8 * sizeof(unsigned)));
   HIP_TRY(hipMemset(c->big.prog, 0, 8 * sizeof(unsigned)));
+  HIP_TRY(hipMalloc(&c->bigflags, 4 * sizeof(unsigned)));
+  HIP_TRY(hipMemset(c->bigflags, 0, 4 * sizeof(unsigned)));
   c->big_ready = true;
   return TNML_OK;
 }
@@ -818,7 +827,7 @@ static int narrow_path(const tnml_ctx *c, int h, int g, int s, int L, int m) {
 }
 
 static int run_narrow(tnml_ctx *c, NarrowParams &n, int path, bool skip_prep = false, hipEvent_t after_update = nullptr,
-                      const BigFront *front = nullptr) {
+                      const BigFront *front = nullptr, unsigned *sig_flag = nullptr, unsigned sig_val = 0) {
   if (path == 0) {
     size_t lds = narrow_lds_bytes(n.h, n.g, n.s, n.L, n.m);
     if (n.fused && !n.prep_ready) lds = std::max(lds, prep_slice_lds_bytes(n.h, n.g, n.s, n.L));   // slice workgroups ride along
@@ -830,7 +839,7 @@ static int run_narrow(tnml_ctx *c, NarrowParams &n, int path, bool skip_prep = f
   if (rc) return rc;
   n.dbg = c->dbg;                       // the capture block is this path's workspace
   n.token = ++c->token;                 // (tags the progress words of the replay that rides in the Jacobi launch)
-  if (!launch_narrow_big(n, c->big, c->stream, c->check_launches, false, skip_prep, after_update, front)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
+  if (!launch_narrow_big(n, c->big, c->stream, c->check_launches, false, skip_prep, after_update, front, sig_flag, sig_val)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
   return TNML_OK;
 }
 
@@ -926,8 +935,8 @@ static bool wide_pipe_fits(const tnml_ctx *c, const WidePipeParams &w) {
 
 // Communicator path: whatever the batch-side stream still holds (f, environments, the exchanged pre-gradient) has to be complete
 // before the context's stream touches it outside a split step.
-static int split_join(tnml_ctx *c) {
-  if (c->zbig_pending) {
+static int split_join(tnml_ctx *c, bool leave_zbig = false) {
+  if (c->zbig_pending && !leave_zbig) {
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_zbig, 0));
     c->zbig_pending = false;
   }
@@ -1396,7 +1405,10 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       if (c->Zbig_valid && k >= 3 && c->Zbig_k == k && c->Zbig_left == left_dir && c->Zbig_act == act_fn && c->Zbig_loss == loss_fn && c->Zbig_T == T &&
           npath == 1 && mode == 0 && !Bdirect_dev)
         zbig = c->Zbig_cols == D * D * g * L && c->Zbig_rows == D * (left_dir ? c->mr(p + 2) : c->ml(p - 1));
-      { int rc = split_join(c); if (rc) return rc; }
+      // (a step fed by Z does not wait for the side stream with an event: the workgroups of its first launch that need Z poll the
+      //  sequence number the side stream leaves behind its chain -- see big_signal_kernel; everything else of that launch starts at once)
+      const bool zpoll = zbig && c->bigflags_enabled && c->zbig_pending;
+      { int rc = split_join(c, zpoll); if (rc) return rc; }
       c->Z_valid = false; c->Zbig_valid = false;
       // ---- wide kernel -----------------------------------------------------------------------
       WideParams w{};
@@ -1460,6 +1472,7 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
         // raw gradient = A_{k-1}^T . Z_k (+ the metric tail): no batch kernel, no slab reduction, no exchange on this stream; it rides
         // in the launch that forms the merged tensor (run_narrow below)
         front.Z = c->zred; front.A = w.ext_core; front.ncols = D * D * g * L; front.red = c->red;
+        if (zpoll) { front.poll_flag = c->bigflags; front.poll_want = c->zsig_seq; front.wait_ev = c->ev_zbig; }
       } else if (!launch_wide(w, nblk, prep_ok ? &prep : nullptr, c->stream, &prep_done))
         return fail(TNML_ERR_ARG, "step at sites (%d,%d): a 32-sample tile of this bond dimension does not fit the batch kernels' LDS", p, p + 1);
       n.prep_ready = prep_done ? 1 : 0;
@@ -1496,8 +1509,20 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
         next_z = mnext > 0 && narrow_path(c, m, gnext, snext, L, mnext) == 1 && zs + kMetricSlots <= (size_t)c->zstride &&
                  lds_z > 0 && lds_z <= 160 * 1024 && D * h <= 2 * c->Mmax && (size_t)D * h * c->b_pad <= (size_t)2 * c->Mmax * c->b_pad;
       }
+      if (next_z) { int rc = ensure_big(c); if (rc) return rc; }          // (the flag words of the hand-offs live with its scratch)
       if (next_z && !c->bigPk) HIP_TRY(hipMalloc(&c->bigPk, (size_t)D * c->Mmax * c->b_pad * sizeof(float)));
-      { int rc = run_narrow(c, n, npath, prep_ahead, next_z ? c->ev_upd_big : nullptr, zbig ? &front : nullptr); if (rc) return rc; }
+      // (a step fed by Z launches no batch kernel of its own: the environment work for the NEXT step's batch kernel rides in this
+      //  step's first launch on this stream, and the side stream's chain starts with the batch kernel itself)
+      const bool ext_in_front = next_z && zbig;
+      if (ext_in_front) {
+        front.ext_Eprev = w.Hprev; front.ext_x_km1 = w.x_km1; front.ext_x_k = w.x_k; front.ext_A = w.ext_core; front.b_pad = c->b_pad;
+        front.ext_Ecur = w.Hcur; front.ext_Pk = c->bigPk;
+        front.ext_acquire = c->ext_on_side;
+      }
+      const bool bsig = next_z && c->bigflags_enabled;
+      if (bsig) ++c->bsig_seq;
+      { int rc = run_narrow(c, n, npath, prep_ahead, next_z ? c->ev_upd_big : nullptr, zbig ? &front : nullptr, bsig ? c->bigflags + 1 : nullptr, c->bsig_seq);
+        if (rc) return rc; }
       prof_end(c, 3);
       if (zbig && !next_z) {
         // a step that took its gradient from Z launched no batch kernel, and none for the next step either: the behind environment
@@ -1508,8 +1533,10 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       if (next_z) {
         // stream2, behind B_new(k): E_k and P'_k = E_k (x) x_k; then the tiled batch kernel "of step k+1" with P'_k in the place of its
         // behind environment (D h rows): f of step k from B_new(k) and the slabs of Z_{k+1}; their sum; the exchange.
-        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upd_big, 0));
-        if (!launch_big_ext(w.Hprev, w.x_km1, w.x_k, w.ext_core, c->b_pad, w.Hcur, c->bigPk, c->stream2)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
+        if (bsig) { if (!launch_big_gate(c->bigflags + 1, c->bsig_seq, c->status, c->stream2)) return fail(TNML_ERR_HIP, "%s", big_launch_error()); }
+        else HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upd_big, 0));
+        c->ext_on_side = !ext_in_front;
+        if (!ext_in_front && !launch_big_ext(w.Hprev, w.x_km1, w.x_k, w.ext_core, c->b_pad, w.Hcur, c->bigPk, c->stream2)) return fail(TNML_ERR_HIP, "%s", big_launch_error());
         WideParams z{};
         z.b = c->b; z.b_pad = c->b_pad; z.L = L;
         z.h = D * h; z.g = gnext; z.hp = h; z.gp = g;
@@ -1526,16 +1553,19 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
         launch_wide_tiled(z, nblk, lds_z, c->stream2);
         launch_reduce(c->zslabs, nblk, c->zstride, z.bsize + kMetricSlots, c->zred, c->stream2);
         if (c->comm) NCCL_TRY(ncclAllReduce(c->zred, c->zred, z.bsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream2));
+        if (c->bigflags_enabled) { ++c->zsig_seq; if (!launch_big_signal(c->bigflags, c->zsig_seq, c->stream2)) return fail(TNML_ERR_HIP, "%s", big_launch_error()); }
         HIP_TRY(hipEventRecord(c->ev_zbig, c->stream2));
         c->zbig_pending = true;
         c->Zbig_valid = true; c->Zbig_k = k + 1; c->Zbig_left = left_dir; c->Zbig_act = act_fn; c->Zbig_loss = loss_fn; c->Zbig_T = T;
         c->Zbig_rows = D * h; c->Zbig_cols = D * D * gnext * L;
-        c->sweep_launches += 3;
+        c->sweep_launches += ext_in_front ? 2 : 3;
         f_by_z = true;
       }
       // batch kernel + reduction (a step fed by Z has neither: its contraction rides in the chain's first launch), then the update:
-      // one launch in LDS, eight through HBM (front, T, weight decay, update, Gram, Jacobi + replay + order, cores, norm environment)
-      c->sweep_launches += (zbig ? 0 : ((fused_now && npath == 0) ? 1 : 2)) + (npath == 1 ? 8 : 1);
+      // one launch in LDS; through HBM eight in the factored form (front products [+ contraction, + next environment], merged tensor +
+      // weight decay, update, Gram, Jacobi + replay + order, cores, two for the norm environment), nine with T = Nh^T . B
+      c->sweep_launches += (zbig ? 0 : ((fused_now && npath == 0) ? 1 : 2)) + (npath == 1 ? ((Bdirect_dev || prep_ahead) ? 9 : 8) : 1);
+      if (zbig) c->step_launches++;           // (counted with the single-launch steps: a step that took its gradient from Z)
       c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
       if (mode == 1) {
         // the behind environment list grew (as update_B does, Network_class.py:637-652); nothing else changes

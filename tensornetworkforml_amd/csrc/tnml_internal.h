@@ -173,26 +173,39 @@ void launch_narrow(const NarrowParams &p, size_t lds_bytes, hipStream_t st);   /
 // Large-tensor path of the same step (kernels_big.hip): HBM scratch, n = min(rows, cols) <= 128.
 struct BigScratch {
   float *Bf;          // [bmax]   merged tensor
-  double *T;          // [bmax]   Nh^T . B
-  double *part;       // [kBigParts][3] block-partial sums
+  double *T;          // [bmax]   Nh^T . B, or (factored form) NL = Nh^T . lab followed by PR = pl . Ng
+  double *part;       // [kBigParts][3] block-partial sums, then {step factor, sum|B|, sum|dv|, L2 sum}
   double *gram;       // [8][128][128] partial Gram matrices
   double2 *rotlog;    // [(kJacobiMaxSweeps * 127 + 2)][64] rotations (c, s) in application order
   double *lam;        // [3][128] eigenvalues by position, sigma^(1/2), sigma^(-1/2) of the kept columns
   int *info;          // rounds applied, sweeps, converged, kept rank, then the eigenvalue order [128]
   double *VW;         // [(rows + cols)][n]  V, then W^T V
   float *Cb;          // [rows][m]  new behind core, contiguous
-  double *T2;         // [rows][m]  (unused since the norm environment became one launch)
-  unsigned *prog;     // [2] progress / final word of the replay that rides in the Jacobi launch (kernels_big.hip)
+  double *T2;         // [rows][m]
+  unsigned *prog;     // [0..6] progress / final word / time-out notes of the replay that rides in the Jacobi launch, [7] arrival
+                      //        counter of the weight-decay kernel's blocks (kernels_big.hip)
 };
 constexpr int kBigMaxN = 128;
-constexpr int kBigParts = 512;
+constexpr int kBigParts = 2048;
 size_t big_jacobi_lds_bytes(int n);
 // false: a launch of the path was illegal or (check) failed; big_launch_error() names it
 // `front`: the raw gradient of a pipelined large-tensor step, red = A^T . Z, formed in the SAME launch as the merged tensor
 // (neither needs the other); without a merged tensor to form it is launched alone, in front of the chain
-struct BigFront { const float *Z; CoreView A; int ncols; float *red; };
+struct BigFront {
+  const float *Z; CoreView A; int ncols; float *red;
+  // optional: the behind environment E_k and P'_k = E_k (x) x_k of the NEXT step's batch kernel in the same launch (big_ext_kernel's work)
+  const float *ext_Eprev = nullptr, *ext_x_km1 = nullptr, *ext_x_k = nullptr; CoreView ext_A{}; int b_pad = 0;
+  float *ext_Ecur = nullptr, *ext_Pk = nullptr;
+  // optional: Z (and what the extension rewrites) belongs to the side stream until poll_flag has reached poll_want (big_signal_kernel);
+  // wait_ev: the event to fall back on where the contraction is launched alone
+  unsigned *poll_flag = nullptr; unsigned poll_want = 0; hipEvent_t wait_ev = nullptr;
+  bool ext_acquire = false;      // the extension's inputs were written on the side stream too (behind the first pipelined step)
+};
 bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t st, bool check, bool prep_only = false,
-                       bool skip_prep = false, hipEvent_t after_update = nullptr, const BigFront *front = nullptr);
+                       bool skip_prep = false, hipEvent_t after_update = nullptr, const BigFront *front = nullptr,
+                       unsigned *sig_flag = nullptr, unsigned sig_val = 0);      // sig_flag: the Gram kernel stores sig_val there (instead of the event)
+bool launch_big_signal(unsigned *flag, unsigned value, hipStream_t st);
+bool launch_big_gate(const unsigned *flag, unsigned want, int *status, hipStream_t st);
 // pipelined large-tensor step: behind environment + (h, d) operand of the pre-gradient; raw gradient = A^T . Z (kernels_big.hip)
 bool launch_big_ext(const float *Eprev, const float *x_km1, const float *x_k, const CoreView &A, int b_pad, float *Ecur, float *Pk,
                     hipStream_t st);

@@ -2,7 +2,7 @@
 """GPU probe: accuracy of the in-kernel Jacobi SVD late in training (the steady state, where it stops after
 few sweeps).  Every step of one pass is run alone with capture on; the device's singular values and the
 product of its two new cores are compared with LAPACK's SVD of the device's own updated merged tensor.
-Usage: python tools/probe_svd_accuracy.py [N] [M] [b] [passes_before] [svd_stop2]"""
+Usage: python tools/probe_svd_accuracy.py [N] [M] [b] [passes_before] [svd_stop2|-] [checked_passes] [rotating_batches]"""
 import os
 import sys
 
@@ -16,12 +16,16 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 b = int(sys.argv[3]) if len(sys.argv) > 3 else 1500
 P = int(sys.argv[4]) if len(sys.argv) > 4 else 10
-STOP = float(sys.argv[5]) if len(sys.argv) > 5 else None
+STOP = float(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] != '-' else None
+CHK = int(sys.argv[6]) if len(sys.argv) > 6 else 2
+NB = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 L, D = 2, 2
 rng = np.random.default_rng(0)
-p = rng.random((b, N), dtype=np.float32) * (rng.random((b, N), dtype=np.float32) > 0.81)
-X = np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32)
-y = rng.integers(0, L, b).astype(np.int32)
+batches = []
+for _ in range(NB):
+    p = rng.random((b, N), dtype=np.float32) * (rng.random((b, N), dtype=np.float32) > 0.81)
+    batches.append((np.stack([np.sin(np.pi * p / 2), np.cos(np.pi * p / 2)], -1).astype(np.float32), rng.integers(0, L, b).astype(np.int32)))
+X, y = batches[0]
 ctx = _hip.Context(N, D, L, M, b)
 if STOP is not None:
     ctx.set_svd_stop(STOP)
@@ -38,7 +42,9 @@ def matricize(B, left):
     return np.transpose(B, (0, 1, 4, 2, 3)).reshape(ml * D * L, D * mr)      # rows (a, d, l)
 
 
-for ps in range(P + 2):
+for ps in range(P + CHK):
+    if NB > 1:
+        ctx.set_input(*batches[ps % NB])
     ctx.forward(want_f=False)
     left = ctx.l_pos == N - 1
     if ps < P:
@@ -74,7 +80,7 @@ for ps in range(P + 2):
         dump.append((Bm.astype(np.float32), m, int(sc[3]), int(sc[55]) if len(sc) > 55 else -1))
     ctx.debug_enable(False)
     os.makedirs('gpurun_out', exist_ok=True)
-    np.savez('gpurun_out/svd_mats_%s.npz' % ('left' if left else 'right'), **{'B%d' % i: d[0] for i, d in enumerate(dump)},
+    np.savez('gpurun_out/svd_mats_%s.npz' % (('left' if left else 'right') if CHK == 2 else 'pass%d' % ps), **{'B%d' % i: d[0] for i, d in enumerate(dump)},
              m=np.array([d[1] for d in dump]), sweeps=np.array([d[2] for d in dump]), rounds=np.array([d[3] for d in dump]))
     print('checked pass (%s): sweeps (count, n) %s' % ('left' if left else 'right', sweeps[:8] + ['...'] + sweeps[len(sweeps) // 2:len(sweeps) // 2 + 3]))
     print('   worst |sigma - lapack| / sigma_max = %.2e ; worst relative error of a kept sigma = %.2e ; '
