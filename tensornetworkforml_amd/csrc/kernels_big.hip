@@ -153,12 +153,13 @@ __global__ __launch_bounds__(kBT) void big_wd_kernel(NarrowParams p, const float
 // (b) from the two cores: Ln.B.Rn = (Nh^T . lab) . (pl . Ng) contracted over the shared bond like the merged tensor itself -- the
 //     merged tensor B and the L2 gradient in ONE loop over s, no T = Nh^T . B in between (a launch of 100 k x 50-term sums less).
 //       NL[h', dk, s, l] = sum_a Nh[a, h'] lab(a, dk, s, l)       PR[s, dk1, f] = sum_c pl(s, dk1, c) Ng[c, f]
-//     are formed by big_front_kernel beside the contraction.
+//     are formed by big_front_kernel beside the contraction (float64: the norm environments range far beyond float32's exponents
+//     along a 784-site chain -- stored as float32 they overflowed at full length).
 //     A workgroup takes 64 elements per pass: waves 0 and 2 form the merged-tensor sums of 32 elements each, waves 1 and 3 the L2
 //     sums of the same elements (the role is wave-uniform: no divergence), two lanes per element splitting the shared bond; the
 //     halves meet by a lane shuffle, the L2 sum crosses to its element's owner through LDS.  (One lane per element with both sums in
 //     its loop: 23 us at C5 -- longer than the three launches it replaced; roles on lanes of the same wave: 38 us.)
-__global__ __launch_bounds__(kBT) void big_merge_wd_kernel(NarrowParams p, float *__restrict__ Bf, const double *__restrict__ NL,
+__global__ __launch_bounds__(kBT, 7) void big_merge_wd_kernel(NarrowParams p, float *__restrict__ Bf, const double *__restrict__ NL,
                                                           const double *__restrict__ PR, double *__restrict__ ws,
                                                           double *__restrict__ part) {
   __shared__ double sGV[64];
@@ -176,43 +177,36 @@ __global__ __launch_bounds__(kBT) void big_merge_wd_kernel(NarrowParams p, float
     const int g_ = q % g; q /= g;
     const int dk1 = q % D; q /= D;
     const int dk = q % D, h_ = q / D;
+    // (one loop shape for whole and partial batches -- clamped index, masked product: the separate tail loops of the first version
+    //  doubled the live registers, 137 VGPRs = 3 waves per SIMD for a launch of 6252 waves)
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int k = k_lo;
     if (which == 0) {
       const float *la = p.lab.base + h_ * p.lab.s_in + dk * p.lab.s_d + l;
       const float *pl = p.pl.base + dk1 * p.pl.s_d + g_ * p.pl.s_out;
-      for (; k + 8 <= k_hi; k += 8) {
+      const int so = p.lab.s_out, si_ = p.pl.s_in;
+      for (int k = k_lo; k < k_hi; k += 8) {
         float lv[8], pv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { lv[u] = la[(k + u) * p.lab.s_out]; pv[u] = pl[(k + u) * p.pl.s_in]; }
+        for (int u = 0; u < 8; ++u) { const int kk = min(k + u, k_hi - 1); lv[u] = la[kk * so]; pv[u] = pl[kk * si_]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k + u >= k_hi) lv[u] = 0.f;
         a0 = fma((double)lv[0], (double)pv[0], a0); a1 = fma((double)lv[1], (double)pv[1], a1);
         a2 = fma((double)lv[2], (double)pv[2], a2); a3 = fma((double)lv[3], (double)pv[3], a3);
         a0 = fma((double)lv[4], (double)pv[4], a0); a1 = fma((double)lv[5], (double)pv[5], a1);
         a2 = fma((double)lv[6], (double)pv[6], a2); a3 = fma((double)lv[7], (double)pv[7], a3);
       }
-      if (k < k_hi) {                                     // the tail in one batch too (clamped index, masked product)
-        float lv[8], pv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int kk = min(k + u, k_hi - 1); lv[u] = la[kk * p.lab.s_out]; pv[u] = pl[kk * p.pl.s_in]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (k + u < k_hi) a0 = fma((double)lv[u], (double)pv[u], a0);
-      }
     } else if (p.l2_flag) {
       const double *nl = NL + ((size_t)(h_ * D + dk) * sb) * L + l;
       const double *pr = PR + (size_t)dk1 * g + g_;
-      for (; k + 8 <= k_hi; k += 8) {
+      const int dg = D * g;
+      for (int k = k_lo; k < k_hi; k += 8) {
         double nv[8], rv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { nv[u] = nl[(size_t)(k + u) * L]; rv[u] = pr[(size_t)(k + u) * D * g]; }
+        for (int u = 0; u < 8; ++u) { const int kk = min(k + u, k_hi - 1); nv[u] = nl[kk * L]; rv[u] = pr[kk * dg]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k + u >= k_hi) nv[u] = 0.0;
         a0 = fma(nv[0], rv[0], a0); a1 = fma(nv[1], rv[1], a1); a2 = fma(nv[2], rv[2], a2); a3 = fma(nv[3], rv[3], a3);
         a0 = fma(nv[4], rv[4], a0); a1 = fma(nv[5], rv[5], a1); a2 = fma(nv[6], rv[6], a2); a3 = fma(nv[7], rv[7], a3);
-      }
-      if (k < k_hi) {
-        double nv[8], rv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int kk = min(k + u, k_hi - 1); nv[u] = nl[(size_t)kk * L]; rv[u] = pr[(size_t)kk * D * g]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (k + u < k_hi) a0 = fma(nv[u], rv[u], a0);
       }
     }
     const double mine = (a0 + a1) + (a2 + a3);
