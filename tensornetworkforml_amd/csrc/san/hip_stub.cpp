@@ -120,6 +120,8 @@ static void check_narrow(const NarrowParams &p) {
     need(p.out_ahead, ((size_t)(p.m - 1) * p.oa_s_m + (size_t)(kD - 1) * p.oa_s_d + (size_t)(p.g - 1) * p.oa_s_g + p.L) * 4, "NarrowParams.out_ahead");
     opt(p.Nh_new, (size_t)p.m * p.m * 8, "NarrowParams.Nh_new");
   }
+  if (p.zpoll_flag) need(p.zpoll_flag, 4, "NarrowParams.zpoll_flag");
+  if (p.done_flag) need(p.done_flag, 4, "NarrowParams.done_flag");
   opt(p.metrics, 2 * 4, "NarrowParams.metrics"); opt(p.counters, 4 * 8, "NarrowParams.counters") /* null in compute_L2_reg alone: the kernel tests it */; need(p.status, 4, "NarrowParams.status");
   if (p.pipe) {
     need(p.zred, (size_t)(p.zsize + kMetricSlots) * 4, "NarrowParams.zred");

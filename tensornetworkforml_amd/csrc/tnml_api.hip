@@ -74,6 +74,10 @@ struct tnml_ctx {
   unsigned zsig_seq = 0, bsig_seq = 0;
   bool bigflags_enabled = true;
   bool ext_on_side = false;                  // the last environment extension of the pipeline ran on the side stream
+  // the same for the two-stream communicator path of the in-LDS step: [0] "Z (all-reduced) is ready", [1] "update launch done"
+  unsigned *splitflags = nullptr;
+  unsigned split_zseq = 0, split_dseq = 0;
+  bool split_flags_enabled = true, split_done_valid = false, split_zsig_valid = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, pev0 = nullptr, pev1 = nullptr;
   // host bookkeeping
   std::vector<int> bond;
@@ -316,7 +320,7 @@ extern "C" int tnml_destroy(tnml_ctx *c) {
   if (c->comm) ncclCommDestroy(c->comm);
   void *ptrs[] = {c->X, c->Xstage, c->y, c->f, c->ftmp, c->ftmp2, c->Lenv, c->Renv, c->cores, c->lab[0], c->lab[1],
                   c->Ln, c->Rn, c->Bnew, c->slabs, c->red, c->metrics, c->scal, c->dbg, c->status, c->tables, c->counters, c->Bscr, c->Bscr2,
-                  c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->zslabs, c->gslabs, c->zred, c->pipe_cnt, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2, c->big.prog, c->bigflags};
+                  c->Xpred_stage, c->Xpred, c->fpred, c->prepB, c->prepG, c->sync, c->zslabs, c->gslabs, c->zred, c->pipe_cnt, c->big.Bf, c->big.T, c->big.part, c->big.gram, c->big.rotlog, c->big.lam, c->big.info, c->big.VW, c->big.Cb, c->big.T2, c->big.prog, c->bigflags, c->splitflags};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   void *pptrs[] = {c->zred2, c->Tbuf[0], c->Tbuf[1], c->TNbuf[0], c->TNbuf[1], c->prepRaw, c->Apub, c->pst_dev, c->pst_cnt, c->pst_flags};
   for (void *p : pptrs) if (p) (void)hipFree(p);
@@ -944,6 +948,7 @@ static int split_join(tnml_ctx *c, bool leave_zbig = false) {
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_bat[c->split_bat], 0));
     c->split_pending = false;
   }
+  c->split_done_valid = false; c->split_zsig_valid = false;
   return TNML_OK;
 }
 
@@ -1317,17 +1322,29 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
     const bool split = pipe && c->comm && c->split_enabled && !c->profile;
     if (pipe && !split) { int rc = split_join(c); if (rc) return rc; }
     if (pipe && split) {
+      // Hand-offs between the two streams: sequence numbers in memory where both sides are kernels of this library (the update
+      // workgroup polls / stores them itself, the side stream runs a one-wave gate kernel and a one-thread signal kernel) -- an
+      // event costs the stream that records or waits 6-7 us even when satisfied (tools/c5_gaps.py); events stay for the first step of a
+      // run and for joining the side stream afterwards.
+      const bool sflags = c->split_flags_enabled;
+      if (sflags && !c->splitflags) {
+        HIP_TRY(hipMalloc(&c->splitflags, 4 * sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(c->splitflags, 0, 4 * sizeof(unsigned), c->stream));
+      }
       if (!c->split_pending) {                 // first split step after anything else: stream2 starts behind the context's stream
         c->split_upd ^= 1;
         HIP_TRY(hipEventRecord(c->ev_upd[c->split_upd], c->stream));
+        c->split_done_valid = false; c->split_zsig_valid = false;
       }
       if (need_prologue) {
         NarrowParams none{};
         wpro.wg0 = 0;
-        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upd[c->split_upd], 0));
+        if (sflags && c->split_done_valid) { if (!launch_big_gate(c->splitflags + 1, c->split_dseq, c->status, c->stream2)) return fail(TNML_ERR_HIP, "%s", big_launch_error()); }
+        else HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upd[c->split_upd], 0));
         launch_step_pipe(none, wpro, wide_pipe_lds_bytes(wpro), c->stream2);
         c->sweep_launches++; c->step_launches++;
         NCCL_TRY(ncclAllReduce(c->zred, c->zred, wpro.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream2));
+        if (sflags) { ++c->split_zseq; if (!launch_big_signal(c->splitflags, c->split_zseq, c->stream2)) return fail(TNML_ERR_HIP, "%s", big_launch_error()); c->split_zsig_valid = true; }
         c->split_bat ^= 1;
         HIP_TRY(hipEventRecord(c->ev_bat[c->split_bat], c->stream2));
         c->split_pending = true;
@@ -1347,7 +1364,8 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
       if (lds_u > 160 * 1024 || lds_b > 160 * 1024) return fail(TNML_ERR_ARG, "internal: pipelined step needs %zu / %zu bytes of LDS", lds_u, lds_b);
       // batch side of step k: needs the behind core the update launch of step k-1 left (event), then B_new(k) (flag in memory)
       const int upd_prev = c->split_upd;
-      HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upd[upd_prev], 0));
+      if (sflags && c->split_done_valid) { if (!launch_big_gate(c->splitflags + 1, c->split_dseq, c->status, c->stream2)) return fail(TNML_ERR_HIP, "%s", big_launch_error()); }
+      else HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upd[upd_prev], 0));
       {
         NarrowParams none{};
         WidePipeParams wb = wp;
@@ -1355,11 +1373,19 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
         launch_step_pipe(none, wb, lds_b, c->stream2);
       }
       // update side of step k: needs Z_k summed over the ranks (the exchange enqueued behind the previous batch-side launch)
-      if (c->split_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_bat[c->split_bat], 0));
+      if (c->split_pending) {
+        if (sflags && c->split_zsig_valid) { n.zpoll_flag = c->splitflags; n.zpoll_want = c->split_zseq; }
+        else HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_bat[c->split_bat], 0));
+      }
+      if (sflags) { n.done_flag = c->splitflags + 1; n.done_val = ++c->split_dseq; }
       launch_step_pipe_update(n, wp, lds_u, c->stream);
-      c->split_upd ^= 1;
-      HIP_TRY(hipEventRecord(c->ev_upd[c->split_upd], c->stream));
+      if (sflags) c->split_done_valid = true;
+      else {
+        c->split_upd ^= 1;
+        HIP_TRY(hipEventRecord(c->ev_upd[c->split_upd], c->stream));
+      }
       if (wp.do_z) NCCL_TRY(ncclAllReduce(c->zred, c->zred, wp.zsize + kMetricSlots, ncclFloat, ncclSum, c->comm, c->stream2));
+      if (sflags) { ++c->split_zseq; if (!launch_big_signal(c->splitflags, c->split_zseq, c->stream2)) return fail(TNML_ERR_HIP, "%s", big_launch_error()); c->split_zsig_valid = true; }
       c->split_bat ^= 1;
       HIP_TRY(hipEventRecord(c->ev_bat[c->split_bat], c->stream2));
       c->split_pending = true;

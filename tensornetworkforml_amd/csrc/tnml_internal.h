@@ -128,6 +128,12 @@ struct NarrowParams {
   double *Apub;            // out: behind core before rounding [D h][m], 1 / sigma [m], next behind norm environment [m][m]
   unsigned *coreflag;      // set to coretoken once Apub and the float32 behind core are stored: helpers project, batch side extends
   unsigned coretoken;
+  // two-stream communicator path without events (tnml_api.hip, split branch): the update workgroup waits for zpoll_flag to reach
+  // zpoll_want before it touches zred (the side stream's all-reduce is followed by a one-thread kernel that stores it), and stores
+  // done_val to done_flag behind an agent-scope release when everything it writes is out (the side stream's next batch launch sits
+  // behind a one-wave kernel that waits for it)
+  const unsigned *zpoll_flag; unsigned zpoll_want;
+  unsigned *done_flag; unsigned done_val;
   unsigned *abort_flag;    // set by any workgroup whose wait timed out; every wait of the launch gives up once it is set
 };
 
