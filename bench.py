@@ -176,6 +176,7 @@ def main():
     ap.add_argument('--pipe-tiles', type=int, default=0, help='sample tiles per batch-side workgroup on steps with a long SVD (tnml_set_step_pipeline(ctx, n), n >= 2)')
     ap.add_argument('--sync-interval', type=int, default=0, help='drain the stream every so many sweep steps (runs under rocprofv3 --pmc)')
     ap.add_argument('--check-launches', action='store_true', help='read the launch status back after every kernel launch')
+    ap.add_argument('--event-handoffs', action='store_true', help='hand-offs between the two streams of a context as events instead of sequence numbers in memory (runs under rocprofv3 --pmc, which serialises dispatches: a polling kernel would wait for a producer that cannot start)')
     ap.add_argument('--no-comm-overlap', action='store_true', help='multi-GPU: one fused launch per step with the all-reduce between launches (round 2) instead of update side / batch side + all-reduce on two streams')
     args = ap.parse_args()
 
@@ -209,6 +210,8 @@ def main():
         os.close(saved_fd)
     if args.no_comm_overlap:
         ctx.set_comm_overlap(False)
+    if args.event_handoffs:
+        ctx.set_flag_handoffs(False)
     if args.sync_interval:
         ctx.set_sync_interval(args.sync_interval)
     if args.check_launches:

@@ -206,6 +206,14 @@ int tnml_set_sync_interval(tnml_ctx *ctx, int n_steps);
  * choice. */
 int tnml_set_narrow_path(tnml_ctx *ctx, int force_large);
 
+/* The hand-offs between the context's two streams (pipelined large-tensor step; update side / batch side + all-reduce of the communicator
+ * path) are sequence numbers in memory by default: the consuming kernel, or a one-wave gate kernel in front of it, polls the word a
+ * one-thread signal kernel (or the producing workgroup itself) stores -- an event dependency costs the stream that records or waits
+ * 6-7 us even when it is satisfied.  Every waiting kernel is enqueued after the kernels it waits for and its wait is bounded
+ * (TNML_ERR_STATE on a time-out), but a tool that lets only ONE kernel run at a time (rocprofv3 --pmc serialises dispatches) keeps the
+ * producer from ever starting: on = 0 (or the environment variable TNML_EVENT_HANDOFFS=1 at tnml_create) uses events everywhere. */
+int tnml_set_flag_handoffs(tnml_ctx *ctx, int on);
+
 /* The forward environment chain (Network.forward, Network_class.py:227-255) runs on the matrix cores for bond dimensions
  * <= 32 (one wave per 16 samples) and as plain FMAs otherwise and in the renormalising calibration pass.  force_plain = 1
  * sends every chain down the plain-FMA kernel (tests, diagnostics); 0 restores the automatic choice. */

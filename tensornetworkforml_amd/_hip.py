@@ -28,7 +28,7 @@ SYMBOLS = [
     'tnml_profile_enable', 'tnml_profile_get', 'tnml_profile_reset', 'tnml_svd_stats', 'tnml_trunc_rank',
     'tnml_update_B', 'tnml_l2_term', 'tnml_svd_split', 'tnml_set_svd_stop', 'tnml_set_narrow_path', 'tnml_predict', 'tnml_set_trunc_threshold',
     'tnml_set_sync_interval', 'tnml_set_step_pipeline', 'tnml_stage_batch', 'tnml_select_batch', 'tnml_get_counters',
-    'tnml_svd_stats_ex', 'tnml_set_persistent', 'tnml_set_chain_path', 'tnml_marker', 'tnml_set_comm_overlap', 'tnml_comm_probe',
+    'tnml_svd_stats_ex', 'tnml_set_persistent', 'tnml_set_chain_path', 'tnml_marker', 'tnml_set_comm_overlap', 'tnml_comm_probe', 'tnml_set_flag_handoffs',
 ]
 
 
@@ -95,6 +95,7 @@ def lib():
         L.tnml_set_chain_path.argtypes = [vp, C.c_int]
         L.tnml_marker.argtypes = [vp, C.c_int]
         L.tnml_set_comm_overlap.argtypes = [vp, C.c_int]
+        L.tnml_set_flag_handoffs.argtypes = [vp, C.c_int]
         L.tnml_comm_probe.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.tnml_predict.argtypes = [vp, f32p, C.c_int, f32p]
         L.tnml_set_trunc_threshold.argtypes = [vp, C.c_double]
@@ -356,6 +357,11 @@ class Context:
         v = C.c_double()
         _chk(lib().tnml_comm_probe(self._h, int(n_floats), int(reps), C.byref(v)))
         return v.value
+
+    def set_flag_handoffs(self, on=True):
+        """hand-offs between the context's two streams as sequence numbers in memory (default) or as events (tools that
+        serialise dispatches: rocprofv3 --pmc)"""
+        _chk(lib().tnml_set_flag_handoffs(self._h, int(bool(on))))
 
     def set_chain_path(self, force_plain):
         """Forward chain as plain FMAs (True) instead of the matrix-core kernel (tests, diagnostics)."""

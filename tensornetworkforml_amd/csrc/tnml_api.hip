@@ -235,6 +235,7 @@ extern "C" int tnml_create(tnml_ctx **out, int N, int D, int L, int Mmax, int b_
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(TNML_ERR_NOGPU, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
   tnml_ctx *c = new tnml_ctx();
+  if (getenv("TNML_EVENT_HANDOFFS") && atoi(getenv("TNML_EVENT_HANDOFFS"))) { c->bigflags_enabled = false; c->split_flags_enabled = false; }   // see tnml_set_flag_handoffs
   // Under the reference truncation policy the bond next to a chain end becomes len(S) =
   // min(D*left, D*L) (Network_class.py:907-910), which exceeds M when M < D*L (the MNIST script
   // runs M = 3, L = 2): size every buffer for that.
@@ -1860,6 +1861,16 @@ extern "C" int tnml_comm_probe(tnml_ctx *c, int n_floats, int reps, double *us_p
 extern "C" int tnml_set_comm_overlap(tnml_ctx *c, int on) {
   if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
   c->split_enabled = on != 0;
+  return TNML_OK;
+}
+
+extern "C" int tnml_set_flag_handoffs(tnml_ctx *c, int on) {
+  if (!c) return fail(TNML_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));          // nothing of either form in flight while the form changes
+  if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
+  c->bigflags_enabled = on != 0; c->split_flags_enabled = on != 0;
+  c->split_done_valid = false; c->split_zsig_valid = false;
   return TNML_OK;
 }
 

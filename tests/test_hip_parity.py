@@ -263,9 +263,10 @@ def test_large_tensor_pipeline_matches_classic_sequence():
     cores = random_canonical_cores(N, M, D, L, scale=M * 0.5 * 0.64 * D, rng=rng)
     hp = (1e-3, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
     res, piped = [], []
-    for pipe in (0, 1):
+    for pipe, flags in ((0, True), (1, True), (1, False)):
         ctx = make_ctx(N, D, L, M, cores, 0, X, y)
         ctx.set_step_pipeline(pipe)
+        ctx.set_flag_handoffs(flags)       # hand-offs between the two streams: sequence numbers in memory (default) / events
         ctx.scale_cores(1.0 / float(np.exp(ctx.forward_logabsmax() / N)))
         ctx.profile_reset()
         outs = []
@@ -276,6 +277,9 @@ def test_large_tensor_pipeline_matches_classic_sequence():
         res.append(outs)
         ctx.close()
     assert piped[0] == 0 and piped[1] >= 2 * (N - 1) - 16, piped       # the pipelined sequence really ran on the mid-chain steps
+    for (ma, fa), (mb, fb) in zip(res[1], res[2]):                        # the same kernels, the same arithmetic: bit for bit
+        np.testing.assert_array_equal(np.asarray(ma), np.asarray(mb))
+        np.testing.assert_array_equal(np.asarray(fa), np.asarray(fb))
     obs = []
     for sw in range(2):
         (m0, f0), (m1, f1) = res[0][sw], res[1][sw]

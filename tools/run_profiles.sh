@@ -14,7 +14,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_kt_$CFG $OUT/prof_fetch_$CFG $OUT/prof_write_$CFG $OUT/prof_mfma_$CFG
-SHORT="--config $CFG --steps 2 --warmup 1 --cpu-steps 0 --no-kernel-profile --no-cold --no-resident --sync-interval 4 $EXTRA"
+# (--event-handoffs: under --pmc only one kernel runs at a time -- a kernel that polls for another stream's sequence number would wait
+#  for a producer that cannot start)
+SHORT="--config $CFG --steps 2 --warmup 1 --cpu-steps 0 --no-kernel-profile --no-cold --no-resident --sync-interval 4 --event-handoffs $EXTRA"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt_$CFG -- python3 $ROOT/bench.py --config $CFG $KT --cpu-steps 0 $EXTRA > $OUT/prof_kt_$CFG.json 2> $OUT/prof_kt_$CFG.err && \
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch_$CFG -- python3 $ROOT/bench.py $SHORT > /dev/null 2> $OUT/prof_fetch_$CFG.err && \
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write_$CFG -- python3 $ROOT/bench.py $SHORT > /dev/null 2> $OUT/prof_write_$CFG.err && \
