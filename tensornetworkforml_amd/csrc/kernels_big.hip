@@ -155,84 +155,81 @@ __global__ __launch_bounds__(kBT) void big_wd_kernel(NarrowParams p, const float
 //       NL[h', dk, s, l] = sum_a Nh[a, h'] lab(a, dk, s, l)       PR[s, dk1, f] = sum_c pl(s, dk1, c) Ng[c, f]
 //     are formed by big_front_kernel beside the contraction (float64: the norm environments range far beyond float32's exponents
 //     along a 784-site chain -- stored as float32 they overflowed at full length).
-//     A workgroup takes 64 elements per pass: waves 0 and 2 form the merged-tensor sums of 32 elements each, waves 1 and 3 the L2
-//     sums of the same elements (the role is wave-uniform: no divergence), two lanes per element splitting the shared bond; the
-//     halves meet by a lane shuffle, the L2 sum crosses to its element's owner through LDS.  (One lane per element with both sums in
-//     its loop: 23 us at C5 -- longer than the three launches it replaced; roles on lanes of the same wave: 38 us.)
-__global__ __launch_bounds__(kBT, 7) void big_merge_wd_kernel(NarrowParams p, float *__restrict__ Bf, const double *__restrict__ NL,
-                                                          const double *__restrict__ PR, double *__restrict__ ws,
-                                                          double *__restrict__ part) {
-  __shared__ double sGV[64];
+//     On the float64 matrix cores (v_mfma_f64_16x16x4_f64), one 16 x 16 output tile per wave:
+//       Bt[n][(m, l)] = sum_s pl(s, n) lab(m, s, l)        GVt[n][(m, l)] = sum_s PR[s, n] NL[m, s, l]       n = (dk1, g), m = (h, dk)
+//     -- ONE plain product each, K = shared bond, with the label index riding in the column index; transposed so that a store
+//     instruction's 16 columns x 4 rows land in contiguous runs of the merged tensor ((m N + n) L + l).  Lane-per-element forms
+//     came first (one lane per element with both sums: 23 us at C5; the two sums on lanes of one wave: 38 us, divergence; two waves
+//     per sum, two lanes per element, 72 VGPRs: 18 us): each re-reads every operand row through L1 for every element -- 120 MB of
+//     L2 -> L1 traffic for a 10 MFLOP product.  Here each operand element is loaded once per tile (16-fold reuse in the matrix core).  Lane maps as in small_gemm_device.h:
+//     A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15], C col = lane & 15, row = (lane >> 4) + 4 reg.
+typedef double big_dvec4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kBT) void big_merge_wd_mfma_kernel(NarrowParams p, float *__restrict__ Bf, const double *__restrict__ NL,
+                                                               const double *__restrict__ PR, double *__restrict__ ws,
+                                                               double *__restrict__ part) {
   const int D = kD, g = p.g, sb = p.s, L = p.L, Bs = p.bsize;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int which = wave & 1, half = lane & 1, slot = 32 * (wave >> 1) + (lane >> 1);     // element slot of the pass, 0..63
-  const int SH = (sb + 1) / 2, k_lo = half * SH, k_hi = min(sb, k_lo + SH);
+  const int N = D * g, MC = p.h * D * L;                 // rows n, columns c = m L + l
+  const int tn = (N + 15) >> 4, tc = (MC + 15) >> 4, ntiles = tn * tc;
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nk = (sb + 3) >> 2;
   double sumB = 0.0, sumD = 0.0, l2 = 0.0;
-  for (int e0 = blockIdx.x * 64; e0 < Bs; e0 += gridDim.x * 64) {          // block-uniform trip count (barriers inside)
-    const int e = e0 + slot;
-    const bool live = e < Bs;
-    const int ee = live ? e : Bs - 1;
-    const int l = ee % L;
-    int q = ee / L;
-    const int g_ = q % g; q /= g;
-    const int dk1 = q % D; q /= D;
-    const int dk = q % D, h_ = q / D;
-    // (one loop shape for whole and partial batches -- clamped index, masked product: the separate tail loops of the first version
-    //  doubled the live registers, 137 VGPRs = 3 waves per SIMD for a launch of 6252 waves)
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (which == 0) {
-      const float *la = p.lab.base + h_ * p.lab.s_in + dk * p.lab.s_d + l;
-      const float *pl = p.pl.base + dk1 * p.pl.s_d + g_ * p.pl.s_out;
-      const int so = p.lab.s_out, si_ = p.pl.s_in;
-      for (int k = k_lo; k < k_hi; k += 8) {
-        float lv[8], pv[8];
+  for (int t = blockIdx.x * (kBT / 64) + wave; t < ntiles; t += gridDim.x * (kBT / 64)) {
+    const int ti = t / tc, tj = t - ti * tc;             // (wave-uniform)
+    const int n_a = min(16 * ti + r, N - 1);             // this lane's operand row of the A side
+    const int c_b = min(16 * tj + r, MC - 1);            // ... column of the B side
+    const int dk1 = n_a / g, g_ = n_a - dk1 * g;
+    const int m_b = c_b / L, l_b = c_b - m_b * L;
+    const float *pa = p.pl.base + dk1 * p.pl.s_d + g_ * p.pl.s_out;                       // + s * pl.s_in
+    const float *pb = p.lab.base + (m_b / D) * p.lab.s_in + (m_b % D) * p.lab.s_d + l_b;  // + s * lab.s_out
+    const double *qa = PR + n_a;                                                          // + s * N
+    const double *qb = NL + (size_t)m_b * sb * L + l_b;                                   // + s * L
+    big_dvec4 b0 = {0.0, 0.0, 0.0, 0.0}, b1 = b0, g0 = b0, g1 = b0;
+    for (int k0 = 0; k0 < nk; k0 += 4) {                 // four k-steps: their operands in flight before the first MFMA
+      double av[4], bv[4], cv[4], dv_[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int kk = min(k + u, k_hi - 1); lv[u] = la[kk * so]; pv[u] = pl[kk * si_]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (k + u >= k_hi) lv[u] = 0.f;
-        a0 = fma((double)lv[0], (double)pv[0], a0); a1 = fma((double)lv[1], (double)pv[1], a1);
-        a2 = fma((double)lv[2], (double)pv[2], a2); a3 = fma((double)lv[3], (double)pv[3], a3);
-        a0 = fma((double)lv[4], (double)pv[4], a0); a1 = fma((double)lv[5], (double)pv[5], a1);
-        a2 = fma((double)lv[6], (double)pv[6], a2); a3 = fma((double)lv[7], (double)pv[7], a3);
+      for (int u = 0; u < 4; ++u) {
+        const int kk = 4 * (k0 + u) + q, kc = min(kk, sb - 1);
+        const bool ok = kk < sb;
+        av[u] = ok ? (double)pa[kc * p.pl.s_in] : 0.0;
+        bv[u] = (double)pb[kc * p.lab.s_out];
+        if (p.l2_flag) { cv[u] = ok ? qa[(size_t)kc * N] : 0.0; dv_[u] = qb[(size_t)kc * L]; }
       }
-    } else if (p.l2_flag) {
-      const double *nl = NL + ((size_t)(h_ * D + dk) * sb) * L + l;
-      const double *pr = PR + (size_t)dk1 * g + g_;
-      const int dg = D * g;
-      for (int k = k_lo; k < k_hi; k += 8) {
-        double nv[8], rv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int kk = min(k + u, k_hi - 1); nv[u] = nl[kk * L]; rv[u] = pr[kk * dg]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (k + u >= k_hi) nv[u] = 0.0;
-        a0 = fma(nv[0], rv[0], a0); a1 = fma(nv[1], rv[1], a1); a2 = fma(nv[2], rv[2], a2); a3 = fma(nv[3], rv[3], a3);
-        a0 = fma(nv[4], rv[4], a0); a1 = fma(nv[5], rv[5], a1); a2 = fma(nv[6], rv[6], a2); a3 = fma(nv[7], rv[7], a3);
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + u < nk) {                               // wave-uniform
+          if (u & 1) b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], b1, 0, 0, 0);
+          else b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], b0, 0, 0, 0);
+          if (p.l2_flag) {
+            if (u & 1) g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[u], dv_[u], g1, 0, 0, 0);
+            else g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[u], dv_[u], g0, 0, 0, 0);
+          }
+        }
       }
     }
-    const double mine = (a0 + a1) + (a2 + a3);
-    const double other = __shfl_xor(mine, 1);
-    const double tot = half == 0 ? mine + other : other + mine;          // lower half of the bond first, on both lanes
-    if (which == 1 && half == 0) sGV[slot] = tot;
-    __syncthreads();
-    if (which == 0 && half == 0 && live) {
-      const float bf = (float)tot;                         // the merged tensor is a float32 tensor (as on the classic path)
-      Bf[e] = bf;
-      const double bv = (double)bf;
-      const double raw = (double)p.red[e];
-      double wdterm;
-      if (p.l2_flag) {
-        const double gv = sGV[slot];
-        l2 += bv * gv;
-        wdterm = 2.0 * (double)p.wd * gv;
-      } else {
-        wdterm = (double)p.wd * bv;
+    const big_dvec4 bacc = b0 + b1, gacc = g0 + g1;
+    const int c = 16 * tj + r;
+    if (c < MC) {
+      const int m = c / L, l = c - m * L;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int n = 16 * ti + q + 4 * reg;
+        if (n < N) {
+          const int e = (m * N + n) * L + l;
+          const float bf = (float)bacc[reg];              // the merged tensor is a float32 tensor (as on the classic path)
+          Bf[e] = bf;
+          const double bval = (double)bf;
+          const double raw = (double)p.red[e];
+          double wdterm;
+          if (p.l2_flag) { l2 += bval * gacc[reg]; wdterm = 2.0 * (double)p.wd * gacc[reg]; }
+          else wdterm = (double)p.wd * bval;
+          const double dv = raw - wdterm;
+          ws[e] = bval; ws[(size_t)Bs + e] = raw; ws[2 * (size_t)Bs + e] = dv; ws[3 * (size_t)Bs + e] = wdterm;
+          sumB += fabs(bval);
+          sumD += fabs(dv);
+        }
       }
-      const double dv = raw - wdterm;
-      ws[e] = bv; ws[(size_t)Bs + e] = raw; ws[2 * (size_t)Bs + e] = dv; ws[3 * (size_t)Bs + e] = wdterm;
-      sumB += fabs(bv);
-      sumD += fabs(dv);
     }
-    __syncthreads();                                       // (sGV is rewritten by the next pass)
   }
   big_wd_tail(part, sumB, sumD, l2);
 }
@@ -956,7 +953,7 @@ __device__ inline void big_poll(const unsigned *flag, unsigned want, int *status
 }
 
 // The contraction and the two small products of the L2 term need nothing from each other: one launch, the contraction's workgroups
-// first (theirs is the longer latency chain), four column chunks each; then NL = Nh^T . lab and PR = pl . Ng (big_merge_wd_kernel).
+// first (theirs is the longer latency chain), four column chunks each; then NL = Nh^T . lab and PR = pl . Ng (big_merge_wd_mfma_kernel).
 __device__ inline void big_nlpr_body(const NarrowParams &p, double *__restrict__ NL, double *__restrict__ PR, int blk, int nblk) {
   const int D = kD, h = p.h, g = p.g, sb = p.s, L = p.L;
   const int nNL = h * D * sb * L, nPR = sb * D * g;
@@ -1073,7 +1070,8 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   }
   const int nbe = std::min((Bs + kBT - 1) / kBT, 2048);          // one element per thread
   const int nb = std::min((Bs + kBT - 1) / kBT, kBigParts);      // kernels that leave block partials
-  const int nb4 = std::min((Bs + kBT / 4 - 1) / (kBT / 4), kBigParts);   // ... at four lanes per element
+  // ... one 16 x 16 tile of [D g] x [h D L] per wave, four waves per workgroup
+  const int nbm = std::min((((D * p.g + 15) / 16) * ((p.h * D * p.L + 15) / 16) + kBT / 64 - 1) / (kBT / 64), kBigParts);
   const float *Bf = p.Bdirect;
 #define BIG(kern, grid, block, lds, ...)                                          \
   do {                                                                            \
@@ -1122,7 +1120,7 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
       BIG(big_front_kernel, dim3(ncontract + next + nlpr), dim3(kBT), lds_f, p, NL, PR, front->Z, front->A, front->ncols, front->red, ncx,
           ncontract, ext, next_x, next, (const unsigned *)front->poll_flag, front->poll_want, front->ext_acquire ? 1 : 0);
     } else if (nlpr) BIG(big_nlpr_kernel, dim3(nlpr), dim3(kBT), 0, p, NL, PR);
-    BIG(big_merge_wd_kernel, dim3(nb4), dim3(kBT), 0, p, s.Bf, (const double *)NL, (const double *)PR, ws, s.part);
+    BIG(big_merge_wd_mfma_kernel, dim3(nbm), dim3(kBT), 0, p, s.Bf, (const double *)NL, (const double *)PR, ws, s.part);
   } else {
     if (!Bf) {
       if (!skip_prep) BIG(big_merge_kernel, dim3(nbe), dim3(kBT), 0, p, s.Bf);
@@ -1132,7 +1130,7 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
     if (prep_only) return true;
     BIG(big_wd_kernel, dim3(nb), dim3(kBT), 0, p, Bf, (const double *)s.T, ws, s.part);
   }
-  BIG(big_update_kernel, dim3(nb), dim3(kBT), 0, p, ws, (const double *)s.part, factored ? nb4 : nb);
+  BIG(big_update_kernel, dim3(nb), dim3(kBT), 0, p, ws, (const double *)s.part, factored ? nbm : nb);
   // B_new is complete: the batch kernel of the NEXT step may start beside the SVD of this one (pipelined large-tensor step)
   if (!sig_flag && after_update && hipEventRecord(after_update, st) != hipSuccess) {
     snprintf(g_big_err, sizeof g_big_err, "hipEventRecord behind big_update_kernel failed");

@@ -238,7 +238,7 @@ hipError_t hipLaunchKernel(const void *fn, dim3 g, dim3 b, void **args, size_t s
   } else if (has("env_chain_kernel")) {
     check_chain(*(const ChainSite **)args[0], *(int *)args[1], *(const float **)args[2], *(const float **)args[3], *(const float **)args[4],
                 has("<true>") ? nullptr : *(float **)args[5], *(float **)args[6], *(int *)args[8], *(int *)args[9]);
-  } else if (has("big_merge_wd_kernel")) { // (NarrowParams, merged tensor out, NL, PR, workspace, block partials): the factored chain's entry
+  } else if (has("big_merge_wd_kernel") || has("big_merge_wd_mfma_kernel")) { // (NarrowParams, merged tensor out, NL, PR, workspace, block partials): the factored chain's entry
     const NarrowParams &n = *(const NarrowParams *)args[0];
     check_narrow(n);
     need(*(float **)args[1], (size_t)n.bsize * 4, "large-tensor path: merged tensor");
