@@ -998,26 +998,140 @@ __device__ inline void big_nlpr_body(const NarrowParams &p, double *__restrict__
     }
   }
 }
+// All three jobs are small matrix products: on the matrix cores, one 16 x 16 output tile per wave, operands straight from memory
+// (each element loaded once per tile, four k-steps in flight).  Lane maps: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15];
+// C col = lane & 15 and row = 4 (lane >> 4) + reg for v_mfma_f32_16x16x4_f32, row = (lane >> 4) + 4 reg for v_mfma_f64_16x16x4_f64.
+// As lane-per-output FMA loops (with the core in LDS) the launch took 19 us at C5, the environment job the longest.
+typedef float big_fvec4 __attribute__((ext_vector_type(4)));
+template <class FA, class FB>
+__device__ inline big_fvec4 big_tile_f32(int nk, FA loadA, FB loadB) {      // loadX(kk): this lane's operand of k index kk (masked by the caller's map)
+  const int q = (threadIdx.x & 63) >> 4;
+  big_fvec4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  for (int k0 = 0; k0 < nk; k0 += 4) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = loadA(4 * (k0 + u) + q); b[u] = loadB(4 * (k0 + u) + q); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + u < nk) {                                                     // wave-uniform
+        if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc0, 0, 0, 0);
+      }
+  }
+  return acc0 + acc1;
+}
+template <class FA, class FB>
+__device__ inline big_dvec4 big_tile_f64(int nk, FA loadA, FB loadB) {
+  const int q = (threadIdx.x & 63) >> 4;
+  big_dvec4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+  for (int k0 = 0; k0 < nk; k0 += 4) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = loadA(4 * (k0 + u) + q); b[u] = loadB(4 * (k0 + u) + q); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + u < nk) {
+        if (u & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc0, 0, 0, 0);
+      }
+  }
+  return acc0 + acc1;
+}
+
+struct BigFrontTiles { int contract_blocks, ext_blocks; };       // workgroups of the first two jobs (four tiles each); the rest: NL, PR
 __global__ __launch_bounds__(kBT) void big_front_kernel(NarrowParams p, double *__restrict__ NL, double *__restrict__ PR,
                                                        const float *__restrict__ Z, CoreView A, int ncols, float *__restrict__ red,
-                                                       int ncx, int ncontract, BigExtArgs ext, int next_x, int next,
+                                                       BigFrontTiles ft, BigExtArgs ext,
                                                        const unsigned *poll_flag, unsigned poll_want, int ext_acquire) {
-  extern __shared__ __attribute__((aligned(16))) float sAc[];
-  const int bid = blockIdx.x;
+  const int bid = blockIdx.x, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nc0 = ft.contract_blocks, nc1 = nc0 + ft.ext_blocks;
   // Z, and the buffers the extension rewrites, belong to the side stream until its chain of the previous step has signalled.  The
-  // contraction READS what that stream wrote (acquire: 56 workgroups); the extension reads it only behind the first pipelined step of
-  // a sweep, whose own extension ran over there (an acquire in each of its 316 workgroups empties this XCD's L2 as often: +9 us).
-  if (poll_flag && bid < ncontract + next) big_poll(poll_flag, poll_want, p.status, bid < ncontract || ext_acquire != 0);
-  if (bid < ncontract) {
-    const int bx = bid % ncx, by = bid / ncx;
-    big_contract_body(Z, A, ncols, red, sAc, bx * (kBT / 64) + (int)(threadIdx.x >> 6), by, bid == 0);
-  } else if (bid < ncontract + next) {
-    // behind environment E_k and P'_k for the batch kernel "of step k+1" on the side stream: they need only what step k-1 left, and
-    // the side stream's chain (as long as the Jacobi kernel) is the shorter for not carrying them
-    const int b = bid - ncontract;
-    big_ext_body(ext, sAc, b % next_x, b / next_x);
+  // contraction READS what that stream wrote (acquire); the extension reads it only behind the first pipelined step of a sweep,
+  // whose own extension ran over there (an acquire in each of its workgroups empties this XCD's L2 as often: +9 us).
+  if (poll_flag && bid < nc1) big_poll(poll_flag, poll_want, p.status, bid < nc0 || ext_acquire != 0);
+  if (bid < nc0) {
+    // ---- raw gradient dB[h'][c] = sum_{i = (h, d)} A(i, h') Z[i][c]  (float32, as the batch kernel's own sums) ------------------
+    const int hp = A.n_in, h = A.n_out, nI = hp * kD, tcn = (ncols + 15) >> 4, ntiles = ((h + 15) >> 4) * tcn;
+    const int t = bid * (kBT / 64) + wave;
+    if (t < ntiles) {
+      const int ti = t / tcn, tj = t - ti * tcn;
+      const int o_a = min(16 * ti + r, h - 1), c_b = min(16 * tj + r, ncols - 1);
+      const float *pa = A.base + (size_t)o_a * A.s_out;
+      const float *pz = Z + c_b;
+      const big_fvec4 acc = big_tile_f32((nI + 3) >> 2,
+          [&](int i) { const int ic = min(i, nI - 1); const float v = pa[(size_t)(ic >> 1) * A.s_in + (ic & 1) * A.s_d]; return i < nI ? v : 0.f; },
+          [&](int i) { return pz[(size_t)min(i, nI - 1) * ncols]; });
+      const int c = 16 * tj + r;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int o = 16 * ti + 4 * q + reg;
+        if (o < h && c < ncols) red[(size_t)o * ncols + c] = acc[reg];
+      }
+    }
+    if (bid == 0 && threadIdx.x < kMetricSlots) red[(size_t)h * ncols + threadIdx.x] = Z[(size_t)nI * ncols + threadIdx.x];
+  } else if (bid < nc1) {
+    // ---- behind environment E_k[h'][s] = sum_{i = (h, d)} A(i, h') (E_{k-1}[h][s] x_{k-1}[s][d]) and P'_k = E_k (x) x_k for the batch
+    //      kernel "of step k+1" on the side stream: they need only what step k-1 left --------------------------------------------------
+    const CoreView &EA = ext.A;
+    const int hp = EA.n_in, h = EA.n_out, nI = hp * kD, b_pad = ext.b_pad, tcn = b_pad >> 4, ntiles = ((h + 15) >> 4) * tcn;
+    const int t = (bid - nc0) * (kBT / 64) + wave;
+    if (t < ntiles) {
+      const int ti = t / tcn, tj = t - ti * tcn;
+      const int o_a = min(16 * ti + r, h - 1), s_b = 16 * tj + r;               // (b_pad is a multiple of 64)
+      const float *pa = EA.base + (size_t)o_a * EA.s_out;
+      const float *pe = ext.Eprev + s_b;
+      const float xm0 = ext.x_km1[(size_t)s_b * kD], xm1 = ext.x_km1[(size_t)s_b * kD + 1];
+      const big_fvec4 acc = big_tile_f32((nI + 3) >> 2,
+          [&](int i) { const int ic = min(i, nI - 1); const float v = pa[(size_t)(ic >> 1) * EA.s_in + (ic & 1) * EA.s_d]; return i < nI ? v : 0.f; },
+          [&](int i) { const int ic = min(i, nI - 1); return pe[(size_t)(ic >> 1) * b_pad] * ((ic & 1) ? xm1 : xm0); });
+      const float x0 = ext.x_k[(size_t)s_b * kD], x1 = ext.x_k[(size_t)s_b * kD + 1];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int o = 16 * ti + 4 * q + reg;
+        if (o < h) {
+          ext.Ecur[(size_t)o * b_pad + s_b] = acc[reg];
+          ext.Pk[(size_t)(2 * o) * b_pad + s_b] = acc[reg] * x0;
+          ext.Pk[(size_t)(2 * o + 1) * b_pad + s_b] = acc[reg] * x1;
+        }
+      }
+    }
   } else {
-    big_nlpr_body(p, NL, PR, bid - ncontract - next, (int)gridDim.x - ncontract - next);
+    // ---- NL[h'][(dk, s, l)] = sum_a Nh[a, h'] lab(a, dk, s, l)   and   PR[(s, dk1)][f] = sum_c pl(s, dk1, c) Ng[c, f]   (float64) -----
+    //      (a missing norm environment is the identity: fed as a unit operand, the product is then an exact copy)
+    const int D = kD, h = p.h, g = p.g, sb = p.s, L = p.L;
+    const int J = D * sb * L, tnl_c = (J + 15) >> 4, tnl = ((h + 15) >> 4) * tnl_c;
+    const int I2 = sb * D, tpr_c = (g + 15) >> 4, tpr = ((I2 + 15) >> 4) * tpr_c;
+    for (int t = (bid - nc1) * (kBT / 64) + wave; t < tnl + tpr; t += ((int)gridDim.x - nc1) * (kBT / 64)) {
+      if (t < tnl) {
+        const int ti = t / tnl_c, tj = t - ti * tnl_c;
+        const int o_a = min(16 * ti + r, h - 1), j_b = min(16 * tj + r, J - 1);
+        const int l = j_b % L, rest = j_b / L, s_ = rest % sb, dk = rest / sb;
+        const float *pb = p.lab.base + dk * p.lab.s_d + s_ * p.lab.s_out + l;
+        const big_dvec4 acc = big_tile_f64((h + 3) >> 2,
+            [&](int a) { const int ac = min(a, h - 1); const double v = p.Nh ? p.Nh[(size_t)ac * h + o_a] : (ac == o_a ? 1.0 : 0.0); return a < h ? v : 0.0; },
+            [&](int a) { return (double)pb[(size_t)min(a, h - 1) * p.lab.s_in]; });
+        const int j = 16 * tj + r;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int o = 16 * ti + q + 4 * reg;
+          if (o < h && j < J) NL[(size_t)o * J + j] = acc[reg];
+        }
+      } else {
+        const int tt = t - tnl, ti = tt / tpr_c, tj = tt - ti * tpr_c;
+        const int i_a = min(16 * ti + r, I2 - 1), f_b = min(16 * tj + r, g - 1);
+        const float *pa = p.pl.base + (i_a / D) * p.pl.s_in + (i_a % D) * p.pl.s_d;
+        const big_dvec4 acc = big_tile_f64((g + 3) >> 2,
+            [&](int c) { const double v = (double)pa[(size_t)min(c, g - 1) * p.pl.s_out]; return c < g ? v : 0.0; },
+            [&](int c) { const int cc = min(c, g - 1); return p.Ng ? p.Ng[(size_t)cc * g + f_b] : (cc == f_b ? 1.0 : 0.0); });
+        const int f = 16 * tj + r;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int i = 16 * ti + q + 4 * reg;
+          if (i < I2 && f < g) PR[(size_t)i * g + f] = acc[reg];
+        }
+      }
+    }
   }
 }
 
@@ -1097,28 +1211,27 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   if (factored) {
     const int nlpr = p.l2_flag ? std::min((p.h * D * p.s * p.L + p.s * D * p.g + kBT - 1) / kBT, 2048) : 0;
     if (front) {
-      const int ncx = (front->ncols + kBT - 1) / kBT, ncontract = ncx * ((front->A.n_out + 7) / 8);
-      const size_t lds = (size_t)front->A.n_in * kD * 8 * sizeof(float);
+      const int wpb = kBT / 64;                                      // one 16 x 16 output tile per wave
       if (front->A.n_out < 1 || front->ncols < 1) {
         snprintf(g_big_err, sizeof g_big_err, "big_front_kernel: core %d x %d x %d, %d columns", front->A.n_in, kD, front->A.n_out, front->ncols);
         return false;
       }
+      BigFrontTiles ft{};
+      ft.contract_blocks = (((front->A.n_out + 15) / 16) * ((front->ncols + 15) / 16) + wpb - 1) / wpb;
       BigExtArgs ext{};
-      int next_x = 0, next = 0;
-      size_t lds_f = lds;
       if (front->ext_Ecur) {
         const CoreView &EA = front->ext_A;
-        const size_t lds_e = (size_t)EA.n_in * kD * ((EA.n_out + 3) & ~3) * sizeof(float);
-        if (EA.n_out < 1 || lds_e > 160 * 1024 || front->b_pad % 64) {
+        if (EA.n_out < 1 || front->b_pad % 64) {
           snprintf(g_big_err, sizeof g_big_err, "big_front_kernel: extension core %d x %d x %d, b_pad %d", EA.n_in, kD, EA.n_out, front->b_pad);
           return false;
         }
         ext = BigExtArgs{front->ext_Eprev, front->ext_x_km1, front->ext_x_k, EA, front->b_pad, front->ext_Ecur, front->ext_Pk};
-        next_x = front->b_pad / 64; next = next_x * ((EA.n_out + 15) / 16);
-        lds_f = std::max(lds, lds_e);
+        ft.ext_blocks = (((EA.n_out + 15) / 16) * (front->b_pad / 16) + wpb - 1) / wpb;
       }
-      BIG(big_front_kernel, dim3(ncontract + next + nlpr), dim3(kBT), lds_f, p, NL, PR, front->Z, front->A, front->ncols, front->red, ncx,
-          ncontract, ext, next_x, next, (const unsigned *)front->poll_flag, front->poll_want, front->ext_acquire ? 1 : 0);
+      const int tl2 = p.l2_flag ? ((p.h + 15) / 16) * ((D * p.s * p.L + 15) / 16) + ((p.s * D + 15) / 16) * ((p.g + 15) / 16) : 0;
+      const int l2_blocks = std::min((tl2 + wpb - 1) / wpb, 1024);
+      BIG(big_front_kernel, dim3(ft.contract_blocks + ft.ext_blocks + l2_blocks), dim3(kBT), 0, p, NL, PR, front->Z, front->A, front->ncols,
+          front->red, ft, ext, (const unsigned *)front->poll_flag, front->poll_want, front->ext_acquire ? 1 : 0);
     } else if (nlpr) BIG(big_nlpr_kernel, dim3(nlpr), dim3(kBT), 0, p, NL, PR);
     BIG(big_merge_wd_mfma_kernel, dim3(nbm), dim3(kBT), 0, p, s.Bf, (const double *)NL, (const double *)PR, ws, s.part);
   } else {

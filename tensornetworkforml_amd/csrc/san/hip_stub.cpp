@@ -281,32 +281,30 @@ hipError_t hipLaunchKernel(const void *fn, dim3 g, dim3 b, void **args, size_t s
     need(*(float **)args[3], ((size_t)A.n_out * nc + kMetricSlots) * 4, "big_contract: raw gradient");
     if (shm < (size_t)A.n_in * kD * 8 * 4) die("big_contract_kernel: %zu bytes of LDS", shm);
     if ((size_t)g.x * 64 < nc || (int)g.y * 8 < A.n_out) die("big_contract_kernel: grid (%u, %u) for %zu columns, %d rows", g.x, g.y, nc, A.n_out);
-  } else if (has("big_front_kernel")) {    // (NarrowParams, NL, PR, Z, core view, ncols, red, ncx, ncontract)
+  } else if (has("big_front_kernel")) {    // (NarrowParams, NL, PR, Z, core view, ncols, red, tile split, BigExtArgs, poll flag, poll value, ext acquire)
     const NarrowParams &n = *(const NarrowParams *)args[0];
     check_narrow(n);
     const CoreView &A = *(const CoreView *)args[4];
     const size_t nc = *(int *)args[5];
-    const int ncx = *(int *)args[7], ncontract = *(int *)args[8];
+    struct Tiles { int contract_blocks, ext_blocks; };
+    const Tiles &ft = *(const Tiles *)args[7];
     if (n.l2_flag) {
       need(*(double **)args[1], (size_t)n.h * kD * n.s * n.L * 8, "big_front: NL");
       need(*(double **)args[2], (size_t)n.s * kD * n.g * 8, "big_front: PR");
       if (*(double **)args[2] < *(double **)args[1] + (size_t)n.h * kD * n.s * n.L) die("big_front: PR overlaps NL");
+      if ((int)g.x <= ft.contract_blocks + ft.ext_blocks) die("big_front_kernel: grid %u leaves no workgroup for the L2 products", g.x);
     }
     need(*(const float **)args[3], ((size_t)A.n_in * kD * nc + kMetricSlots) * 4, "big_front: Z");
     need(A.base, view_extent(A, 1) * 4, "big_front: core");
     need(*(float **)args[6], ((size_t)A.n_out * nc + kMetricSlots) * 4, "big_front: raw gradient");
-    if (shm < (size_t)A.n_in * kD * 8 * 4) die("big_front_kernel: %zu bytes of LDS", shm);
-    if ((size_t)ncx * 256 < nc || ncontract != ncx * ((A.n_out + 7) / 8) || (int)g.x < ncontract)
-      die("big_front_kernel: grid %u, %d x %d contraction workgroups for %zu columns, %d rows", g.x, ncx, ncontract / (ncx ? ncx : 1), nc, A.n_out);
     if ((size_t)A.n_out * nc != (size_t)n.bsize) die("big_front_kernel: gradient %d x %zu, merged tensor %d", A.n_out, nc, n.bsize);
-    if (*(const unsigned **)args[12]) need(*(const unsigned **)args[12], 4, "big_front: sequence number of the side stream");
-    const BigExtArgs &ea = *(const BigExtArgs *)args[9];
-    const int next_x = *(int *)args[10], next = *(int *)args[11];
-    if (next) {
-      check_big_ext(ea, shm);
-      if (next_x * 64 != ea.b_pad || next != next_x * ((ea.A.n_out + 15) / 16)) die("big_front_kernel: %d x %d extension workgroups for b_pad %d, %d bond indices", next_x, next / (next_x ? next_x : 1), ea.b_pad, ea.A.n_out);
+    if ((size_t)ft.contract_blocks * 4 < (size_t)((A.n_out + 15) / 16) * ((nc + 15) / 16)) die("big_front_kernel: %d workgroups for the contraction's tiles", ft.contract_blocks);
+    if (*(const unsigned **)args[9]) need(*(const unsigned **)args[9], 4, "big_front: sequence number of the side stream");
+    const BigExtArgs &ea = *(const BigExtArgs *)args[8];
+    if (ft.ext_blocks) {
+      check_big_ext(ea, (size_t)1 << 20);                      // (no LDS in this form)
+      if (ea.b_pad % 64 || (size_t)ft.ext_blocks * 4 < (size_t)((ea.A.n_out + 15) / 16) * (ea.b_pad / 16)) die("big_front_kernel: %d workgroups for the extension's tiles, b_pad %d", ft.ext_blocks, ea.b_pad);
     }
-    if ((int)g.x < ncontract + next + (n.l2_flag ? 1 : 0)) die("big_front_kernel: grid %u for %d + %d workgroups and the L2 products", g.x, ncontract, next);
   } else if (has("big_signal_kernel")) {   // (flag, value)
     need(*(unsigned **)args[0], 4, "big_signal: flag word");
   } else if (has("big_gate_kernel")) {     // (flag, want, status)
