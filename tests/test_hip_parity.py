@@ -312,12 +312,14 @@ def test_rccl_exchange_beside_the_svd(monkeypatch):
     cores32 = [c.astype(np.float32) for c in st.cores]
     hp = (1e-3, 1e-3, True, 'softmax', 'full_cross_ent', 0.1, 'fixed')
     res, us = {}, {}
-    for name, force, overlap in (('no communicator', '0', True), ('fused + all-reduce between launches', '1', False), ('two streams', '1', True)):
+    for name, force, overlap, flags in (('no communicator', '0', True, True), ('fused + all-reduce between launches', '1', False, True),
+                                        ('two streams', '1', True, True), ('two streams, event hand-offs', '1', True, False)):
         monkeypatch.setenv('TNML_FORCE_COMM', force)
         ctx = make_ctx(N, D, L, M, cores32, 0, X, y)
         ctx.set_persistent(0)
         tdist.attach_comm(ctx, 0, 1)
         ctx.set_comm_overlap(overlap)
+        ctx.set_flag_handoffs(flags)
         outs = []
         for sw in range(4):
             ctx.forward(want_f=False)
@@ -335,11 +337,12 @@ def test_rccl_exchange_beside_the_svd(monkeypatch):
         res[name] = outs
         ctx.close()
     print('device time per step (us):', {k: round(v, 2) for k, v in us.items()})
-    for other in ('fused + all-reduce between launches', 'two streams'):
+    for other in ('fused + all-reduce between launches', 'two streams', 'two streams, event hand-offs'):
         for a, b_ in zip(res['no communicator'], res[other]):
             for x, y_ in zip(a, b_):
                 np.testing.assert_array_equal(np.asarray(x), np.asarray(y_))
     assert us['two streams'] - us['no communicator'] < 3.0, us         # observed 1.4 (9.9 with events)
+    assert us['two streams, event hand-offs'] > us['two streams'] + 3.0, us     # (the events are what the sequence numbers replaced: observed +8.5)
     assert abs(us['fused + all-reduce between launches'] - us['no communicator']) < 3.0, us
 
 
