@@ -813,7 +813,7 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_kernel(WideParams
         for (int it = 0; it < dm.IP / 16; ++it) {
           const float *ap = w.sBp + (it * 16 + r) * dm.RS + q * L + l;      // B'[i][(j, l)], j = 4 kk + q
           fvec4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 5
+// (run-time trip count: `#pragma unroll 5` here was refused by the optimizer -- "loop not unrolled" -- and is gone)
           for (int kk = 0; kk < dm.JP / 4; ++kk)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * L], bq[kk * 4 * kTSP], acc, 0, 0, 0);
           const float *pp = w.sPp + (it * 16 + 4 * q) * kTSP + st * 16 + r;
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_kernel(WideParams
       const float *ap = w.sA + q * dm.HS + ht * 16 + r;
       const float *bq = w.sPp + q * kTSP + st * 16 + r;
       fvec4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 5
+// (run-time trip count: `#pragma unroll 5` here was refused by the optimizer -- "loop not unrolled" -- and is gone)
       for (int kk = 0; kk < dm.KA / 4; ++kk)
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * dm.HS], bq[kk * 4 * kTSP], acc, 0, 0, 0);
 #pragma unroll
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(Wide
         const float *bq = w.sQp + q * kTSP + st * 16 + r;
         const float *ap = w.sBc + r * dm.RS + q * L + l;                    // B'[i][(j, l)], j = 4 kk + q
         fvec4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 5
+// (run-time trip count: `#pragma unroll 5` here was refused by the optimizer -- "loop not unrolled" -- and is gone)
         for (int kk = 0; kk < dm.JP / 4; ++kk)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * L], bq[kk * 4 * kTSP], acc, 0, 0, 0);
         const float *pp = w.sPp + (it * 16 + 4 * q) * kTSP + st * 16 + r;

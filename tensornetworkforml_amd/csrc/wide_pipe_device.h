@@ -390,7 +390,7 @@ __device__ __forceinline__ bool wide_pipe_block(const WP &p, float *smem) {
         const float *bq = w.sQp + q * kPTSP + st * 16 + r;
         const float *ap = w.sBp + (it * 16 + r) * dm.RS + q * L + l;
         fvec4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 5
+// (run-time trip count: `#pragma unroll 5` here was refused by the optimizer -- "loop not unrolled" -- and is gone)
         for (int kk = 0; kk < dm.JP / 4; ++kk)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * L], bq[kk * 4 * kPTSP], acc, 0, 0, 0);
         const float *pp = w.sPp + (it * 16 + 4 * q) * kPTSP + st * 16 + r;
