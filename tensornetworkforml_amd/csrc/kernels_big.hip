@@ -303,13 +303,17 @@ __global__ __launch_bounds__(256) void big_gram_kernel(const float *__restrict__
 }
 
 // ---- two-sided Jacobi on the packed symmetric matrix, rotations logged ------------------------------------------
-// Block (P, Q), P <= Q, of the current pairing lives at 4 doubles [e(2P,2Q), e(2P,2Q+1), e(2P+1,2Q), e(2P+1,2Q+1)]
-// (slot 2 of a diagonal block is unused).  Same schedule, look-ahead parameters and stopping rule as the
+// Block (P, Q), P <= Q, of the current pairing has the components [e(2P,2Q), e(2P,2Q+1), e(2P+1,2Q), e(2P+1,2Q+1)]
+// (component 2 of a diagonal block is unused).  Same schedule, look-ahead parameters and stopping rule as the
 // in-LDS kernel (kernels_narrow.hip phase 7); see there for the derivation.
 __device__ inline int blk_index(int P, int Q, int np) { return P * np - P * (P - 1) / 2 + (Q - P); }
-__device__ inline int elem_slot(int a, int b, int np) {       // element (a, b) of the symmetric matrix, any order
+// Storage: FOUR PLANES of nblk doubles -- component c = 2 (row & 1) + (col & 1) of block b at [c * nblk + b].  (Until late in round 3
+// the four components of a block sat together, 32 bytes per block: the 16-byte reads of consecutive blocks were 2-way and the
+// scattered 8-byte writes ~4-way bank conflicts -- SQ_LDS_BANK_CONFLICT was 56 % of SQ_LDS_IDX_ACTIVE, a quarter of the kernel's
+// cycles.  Consecutive blocks are now 8 bytes apart in every plane.)
+__device__ inline int elem_slot(int a, int b, int np, int nblk) {       // element (a, b) of the symmetric matrix, any order
   const int lo = min(a, b), hi = max(a, b);
-  return 4 * blk_index(lo >> 1, hi >> 1, np) + 2 * (lo & 1) + (hi & 1);
+  return (2 * (lo & 1) + (hi & 1)) * nblk + blk_index(lo >> 1, hi >> 1, np);
 }
 
 struct BigJacobiArgs {
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
   const int n = a.n, m = a.m, np = n / 2, ne = n;
   const int nblk = np * (np + 1) / 2;
   double *G0 = (double *)smem_raw, *G1 = G0 + 4 * (size_t)nblk;
-  double *dCS = G1 + 4 * (size_t)nblk;            // [2][np][4]
+  double *dCS = G1 + 4 * (size_t)nblk;            // [2][4 np]: per buffer t[np], c0[np] as doubles, then (t, c0)[np] as float2
   double *dRed = dCS + 8 * (size_t)np;            // 64
   int *sPi = (int *)(dRed + 64), *sPiInv = sPi + ne, *sFlag = sPiInv + ne;     // sFlag[2..3]: round index + 1 of the last big rotation
 
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
       e11 += Gp[(size_t)(2 * P) * n + 2 * Q]; e12 += Gp[(size_t)(2 * P) * n + 2 * Q + 1];
       e21 += Gp[(size_t)(2 * P + 1) * n + 2 * Q]; e22 += Gp[(size_t)(2 * P + 1) * n + 2 * Q + 1];
     }
-    G0[4 * b] = e11; G0[4 * b + 1] = e12; G0[4 * b + 2] = e21; G0[4 * b + 3] = e22;
+    G0[b] = e11; G0[nblk + b] = e12; G0[2 * nblk + b] = e21; G0[3 * nblk + b] = e22;
     if (P == Q) trp += e11 + e22;
   }
   for (int pos = tid; pos < ne; pos += NT) {
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
   for (int e = tid; e < 4 * nblk; e += NT) G0[e] = __builtin_amdgcn_ldexp(G0[e], -sc_exp);
   __syncthreads();
 
-  auto diag = [&](const double *G, int j) { return G[4 * blk_index(j >> 1, j >> 1, np) + 3 * (j & 1)]; };
+  auto diag = [&](const double *G, int j) { return G[3 * (j & 1) * nblk + blk_index(j >> 1, j >> 1, np)]; };
   auto kept_scale = [&](const double *G) -> double {
     for (int j = tid; j < n; j += NT) {
       const double lj = diag(G, j);
@@ -551,11 +555,11 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
       Q = P + rem;
     }
     const int c1 = sPi[2 * Q], c2 = sPi[2 * Q + 1], o1 = sPi[2 * P], o2 = sPi[2 * P + 1];
-    itSrc[u] = 4 * blk_index(P, Q, np);
-    itQ[u] = 4 * Q; itP[u] = 4 * P;
+    itSrc[u] = blk_index(P, Q, np);
+    itQ[u] = Q; itP[u] = P;
     itDiag[u] = P == Q;
-    itD11[u] = elem_slot(o1, c1, np); itD12[u] = elem_slot(o1, c2, np);
-    itD21[u] = elem_slot(o2, c1, np); itD22[u] = elem_slot(o2, c2, np);
+    itD11[u] = elem_slot(o1, c1, np, nblk); itD12[u] = elem_slot(o1, c2, np, nblk);
+    itD21[u] = elem_slot(o2, c1, np, nblk); itD22[u] = elem_slot(o2, c2, np, nblk);
   }
   // item slots this WAVE runs (wave-uniform: slot u is valid for a prefix of the worker threads)
   int wave_items = 0;
@@ -566,8 +570,8 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
   int pa = 0, pb = 1;
   if (isParam) { pa = sPiInv[2 * tid]; pb = sPiInv[2 * tid + 1]; }
   const int pA = pa >> 1, ra = pa & 1, pB = pb >> 1, rb = pb & 1;
-  const int slotAA = 4 * blk_index(pA, pA, np), slotBB = 4 * blk_index(pB, pB, np);
-  const int slotAB = 4 * blk_index(min(pA, pB), max(pA, pB), np);
+  const int slotAA = blk_index(pA, pA, np), slotBB = blk_index(pB, pB, np);
+  const int slotAB = blk_index(min(pA, pB), max(pA, pB), np);
 
   int sweeps = 0, converged = 0, cur = 0, rounds = 0;
   double *Gc = G0, *Gn = G1;
@@ -575,24 +579,24 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
   if (n > 1) {
     kept2 = kept_scale(Gc);
     if (tid == 0) { sFlag[2] = 0; sFlag[3] = 0; }
-    // Rotation slot of pair k in dCS (4 doubles): [0] t, [1] c0 as doubles (float32-exact values), [2] the same two as a
+    // Rotation of pair k in a dCS buffer: t at [k], c0 at [np + k] as doubles (float32-exact values), and the same two at [2 np ..) as a
     // float2 for the look-ahead chain -- the scheme of the in-LDS kernel (kernels_narrow.hip phase 7, jacobi_rot_f32): the
     // dependent chain that sets the length of a round runs in float32, the threads that APPLY a rotation refine its cosine
     // to float64 themselves (rot_corr), and the log for the replay kernel gets the refined (c, s) off the critical path.
     const float kept_lo = 1e-36f;
     const __amdgpu_buffer_rsrc_t rlog = sc1_rsrc(a.rotlog);
-    auto publish = [&](double *o, const RotT &r, int applied, size_t log_at) {
-      *reinterpret_cast<double2 *>(o) = make_double2((double)r.t, (double)r.c0);
-      *reinterpret_cast<float2 *>(o + 2) = make_float2(r.t, r.c0);
+    auto publish = [&](double *buf, int pair, const RotT &r, int applied, size_t log_at) {
+      buf[pair] = (double)r.t; buf[np + pair] = (double)r.c0;
+      reinterpret_cast<float2 *>(buf + 2 * np)[pair] = make_float2(r.t, r.c0);
       if (r.level >= 2) sFlag[2 + (applied & 1)] = applied + 1;
       const double c = (double)r.c0 * rot_corr((double)r.t, (double)r.c0);
       st_sc1_b128(rlog, (unsigned)(log_at * sizeof(double2)), __builtin_bit_cast(tn_uvec4, make_double2(c, c * (double)r.t)));
     };
     if (isParam) {
-      const int sl = 4 * blk_index(tid, tid, np);
-      const RotT r = jacobi_rot_f32((float)Gc[sl], (float)Gc[sl + 3], (float)Gc[sl + 1], fmaxf((float)kept2, kept_lo), (float)abs2,
+      const int sl = blk_index(tid, tid, np);
+      const RotT r = jacobi_rot_f32((float)Gc[sl], (float)Gc[3 * nblk + sl], (float)Gc[nblk + sl], fmaxf((float)kept2, kept_lo), (float)abs2,
                                     (float)a.stop2);
-      publish(dCS + (cur * np + tid) * 4, r, 0, (size_t)tid);
+      publish(dCS + cur * np * 4, tid, r, 0, (size_t)tid);
     }
     __syncthreads();
     // sliding window, as in the in-LDS kernel (kernels_narrow.hip phase 7): stop as soon as ne - 1 consecutive rounds applied no
@@ -605,21 +609,19 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
         if (isParam) {
           // look-ahead: pair `tid` of the NEXT round is (a, b) in today's positions; its three elements after today's
           // rotations, in float32
-          const float2 fA = *reinterpret_cast<const float2 *>(csc + 4 * pA + 2);     // (t, c0) of pair A
-          const float2 fB = *reinterpret_cast<const float2 *>(csc + 4 * pB + 2);
-          const double2 dA = *reinterpret_cast<const double2 *>(Gc + slotAA);
-          const double bA = Gc[slotAA + 3];
-          const double2 dB = *reinterpret_cast<const double2 *>(Gc + slotBB);
-          const double bB = Gc[slotBB + 3];
+          const float2 fA = reinterpret_cast<const float2 *>(csc + 2 * np)[pA];      // (t, c0) of pair A
+          const float2 fB = reinterpret_cast<const float2 *>(csc + 2 * np)[pB];
+          const double2 dA = make_double2(Gc[slotAA], Gc[nblk + slotAA]);
+          const double bA = Gc[3 * nblk + slotAA];
+          const double2 dB = make_double2(Gc[slotBB], Gc[nblk + slotBB]);
+          const double bB = Gc[3 * nblk + slotBB];
           double2 r0, r1;
           if (pA < pB) {
-            r0 = *reinterpret_cast<const double2 *>(Gc + slotAB);
-            r1 = *reinterpret_cast<const double2 *>(Gc + slotAB + 2);
+            r0 = make_double2(Gc[slotAB], Gc[nblk + slotAB]);
+            r1 = make_double2(Gc[2 * nblk + slotAB], Gc[3 * nblk + slotAB]);
           } else if (pA > pB) {
-            const double2 s0 = *reinterpret_cast<const double2 *>(Gc + slotAB);
-            const double2 s1 = *reinterpret_cast<const double2 *>(Gc + slotAB + 2);
-            r0 = make_double2(s0.x, s1.x);
-            r1 = make_double2(s0.y, s1.y);
+            r0 = make_double2(Gc[slotAB], Gc[2 * nblk + slotAB]);               // (the stored block is the transpose)
+            r1 = make_double2(Gc[nblk + slotAB], Gc[3 * nblk + slotAB]);
           } else {
             r0 = dA;
             r1 = make_double2(dA.y, bA);
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
           const float h1 = ra ? fmaf(sA, q0y, cA * q1y) : fmaf(cA, q0y, -sA * q1y);
           const float ng = rb ? fmaf(sB, h0, cB * h1) : fmaf(cB, h0, -sB * h1);
           const RotT r = jacobi_rot_f32(na, nb, ng, fmaxf((float)kept2, kept_lo), (float)abs2, (float)a.stop2);
-          publish(dCS + ((cur ^ 1) * np + tid) * 4, r, rounds + 1, (size_t)(rounds + 1) * np + tid);
+          publish(dCS + (cur ^ 1) * np * 4, tid, r, rounds + 1, (size_t)(rounds + 1) * np + tid);
         }
         if (tid < 64) {
           // wave 0 holds every parameter thread: all of its log stores but the one just issued are complete -> the entries of
@@ -651,10 +653,10 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
           double2 tq[K], tp[K], r0[K], r1[K];
 #pragma unroll
           for (int u = 0; u < K; ++u) {
-            tq[u] = *reinterpret_cast<const double2 *>(csc + itQ[u]);       // (t, c0) of the column pair
-            tp[u] = *reinterpret_cast<const double2 *>(csc + itP[u]);       // ... of the row pair
-            r0[u] = *reinterpret_cast<const double2 *>(Gc + itSrc[u]);
-            r1[u] = *reinterpret_cast<const double2 *>(Gc + itSrc[u] + 2);
+            tq[u] = make_double2(csc[itQ[u]], csc[np + itQ[u]]);            // (t, c0) of the column pair
+            tp[u] = make_double2(csc[itP[u]], csc[np + itP[u]]);            // ... of the row pair
+            r0[u] = make_double2(Gc[itSrc[u]], Gc[nblk + itSrc[u]]);
+            r1[u] = make_double2(Gc[2 * nblk + itSrc[u]], Gc[3 * nblk + itSrc[u]]);
             if (itDiag[u]) r1[u].x = r0[u].y;
           }
           double n11[K], n12[K], n21[K], n22[K];
