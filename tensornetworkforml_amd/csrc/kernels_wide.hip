@@ -939,7 +939,7 @@ __host__ __device__ inline WideTiledSmem wide_tiled_carve(float *base, WideMfmaD
   float *q = base;
   w.sX = q; q += 3 * kTS * kD;
   w.sF = q; q += L * kTS;
-  w.sGl = q; q += L * kTS;
+  w.sGl = q; q += L * kTSP;            // (padded stride: the gradient GEMM reads rows l of it from lanes of one bank group)
   w.sPp = q; q += d.IP * kTSP;
   w.sQp = q; q += d.JP * kTSP;
   w.sH = q; q += up(h, 16) * kTSP;
@@ -1126,10 +1126,10 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(Wide
       float m_abs = 0.f;
       int m_cor = 0, m_nf = 0;
       if (s < p.b) {
-        act_and_lossder(w.sF + tid, kTS, w.sGl + tid, w.sGl + tid, kTS, L, p.y[s], p.act_fn, p.loss_fn, p.T, m_abs,
+        act_and_lossder(w.sF + tid, kTS, w.sGl + tid, w.sGl + tid, kTSP, L, p.y[s], p.act_fn, p.loss_fn, p.T, m_abs,
                         m_cor, m_nf);
       } else {
-        for (int l = 0; l < L; ++l) w.sGl[l * kTS + tid] = 0.f;
+        for (int l = 0; l < L; ++l) w.sGl[l * kTSP + tid] = 0.f;
       }
       sMet[0][tid] = (float)m_cor; sMet[1][tid] = m_abs; sMet[2][tid] = (float)m_nf;
     }
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(Wide
       const int j = nc / L, l = nc - j * L;
       const float *ap = w.sP + (it * 16 + r) * kTSP + q;
       const float *bq = w.sQ + j * kTSP + q;
-      const float *gq = w.sGl + l * kTS + q;
+      const float *gq = w.sGl + l * kTSP + q;      // (stride kTS = 32 floats put every label row on the same banks: a 10-way conflict per k-step at L = 10)
       fvec4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < kTS / 4; ++kk)
