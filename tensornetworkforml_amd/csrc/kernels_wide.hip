@@ -646,6 +646,7 @@ __global__ __launch_bounds__(kWideThreads) void f_only_kernel(WideParams p, int 
 // ------------------------------------------------------------------------------------------
 constexpr int kMfmaThreads = 512;
 constexpr int kTSP = kTS + 1;           // sample stride of the LDS operand arrays (bank spread)
+constexpr int kTSA = kTS + 2;           // ... of the arrays the tiled kernel's gradient GEMM reads as [row][sample] (2 mod 32)
 
 __host__ __device__ inline int up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -939,12 +940,12 @@ __host__ __device__ inline WideTiledSmem wide_tiled_carve(float *base, WideMfmaD
   float *q = base;
   w.sX = q; q += 3 * kTS * kD;
   w.sF = q; q += L * kTS;
-  w.sGl = q; q += L * kTSP;            // (padded stride: the gradient GEMM reads rows l of it from lanes of one bank group)
+  w.sGl = q; q += L * kTSA;            // (operands of the gradient GEMM at the stride kTSA: see there)
   w.sPp = q; q += d.IP * kTSP;
   w.sQp = q; q += d.JP * kTSP;
   w.sH = q; q += up(h, 16) * kTSP;
-  w.sP = q; q += d.I3 * kTSP;
-  w.sQ = q; q += d.J3 * kTSP;
+  w.sP = q; q += d.I3 * kTSA;
+  w.sQ = q; q += d.J3 * kTSA;
   w.U = q;
   constexpr int RPI = 64 / kTS;
   float *a = q;
@@ -1040,7 +1041,7 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(Wide
       const int dd = j >= g ? 1 : 0;
       v = sXp[sl * kD + dd] * (p.Gcur ? w.rG[(j - dd * g) * kTS + sl] : 1.0f);
     }
-    w.sQ[j * kTSP + sl] = v;
+    w.sQ[j * kTSA + sl] = v;
   }
   __syncthreads();
   if (p.do_ext) {                                       // H[hn][s] = sum_i A[i][hn] P'[i][s], all waves
@@ -1126,17 +1127,17 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(Wide
       float m_abs = 0.f;
       int m_cor = 0, m_nf = 0;
       if (s < p.b) {
-        act_and_lossder(w.sF + tid, kTS, w.sGl + tid, w.sGl + tid, kTSP, L, p.y[s], p.act_fn, p.loss_fn, p.T, m_abs,
+        act_and_lossder(w.sF + tid, kTS, w.sGl + tid, w.sGl + tid, kTSA, L, p.y[s], p.act_fn, p.loss_fn, p.T, m_abs,
                         m_cor, m_nf);
       } else {
-        for (int l = 0; l < L; ++l) w.sGl[l * kTSP + tid] = 0.f;
+        for (int l = 0; l < L; ++l) w.sGl[l * kTSA + tid] = 0.f;
       }
       sMet[0][tid] = (float)m_cor; sMet[1][tid] = m_abs; sMet[2][tid] = (float)m_nf;
     }
     // P[i][s] = H[h][s] x_k[s][d] (the A operand of the gradient GEMM)
     for (int e = tid; e < dm.I3 * kTS; e += NT) {
       const int sl = e % kTS, i = e / kTS;
-      w.sP[i * kTSP + sl] = i < h * kD ? w.sH[(i >> 1) * kTSP + sl] * sXk[sl * kD + (i & 1)] : 0.f;
+      w.sP[i * kTSA + sl] = i < h * kD ? w.sH[(i >> 1) * kTSP + sl] * sXk[sl * kD + (i & 1)] : 0.f;
     }
     __syncthreads();
     if (tid < 3) {
@@ -1159,9 +1160,13 @@ __global__ __launch_bounds__(kMfmaThreads) void wide_step_mfma_tiled_kernel(Wide
       const int n = nt * 16 + r;
       const int nc = min(n, NN - 1);
       const int j = nc / L, l = nc - j * L;
-      const float *ap = w.sP + (it * 16 + r) * kTSP + q;
-      const float *bq = w.sQ + j * kTSP + q;
-      const float *gq = w.sGl + l * kTSP + q;      // (stride kTS = 32 floats put every label row on the same banks: a 10-way conflict per k-step at L = 10)
+      // The three operands are read as [row(lane & 15)][4 kk + (lane >> 4)]: a 32-lane bank group holds 16 rows x 2 consecutive
+      // samples, which sit on distinct banks when the row stride is 2 mod 32 (kTSA = 34).  At the odd stride kTSP = 33 of the other
+      // arrays rows r, q = 1 and r + 1, q = 0 collide (2-way); the label rows of the loss derivative at stride 32 all shared their
+      // banks (10-way at ten labels): SQ_LDS_BANK_CONFLICT was 74 % of SQ_LDS_IDX_ACTIVE, half of the kernel's cycles.
+      const float *ap = w.sP + (it * 16 + r) * kTSA + q;
+      const float *bq = w.sQ + j * kTSA + q;
+      const float *gq = w.sGl + l * kTSA + q;
       fvec4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < kTS / 4; ++kk)
