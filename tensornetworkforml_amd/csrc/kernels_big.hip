@@ -728,8 +728,8 @@ __global__ __launch_bounds__(1024) void big_jacobi_kernel(BigJacobiArgs a) {
 }
 
 // ---- the two new cores: short side V[kk][pos_j] sigma_j^(1/2), long side (W^T V)[x][pos_j] sigma_j^(-1/2) ------------
-__global__ __launch_bounds__(kBT) void big_cores_kernel(NarrowParams p, const double *__restrict__ lam3, const int *__restrict__ info,
-                                                       const double *__restrict__ VW, float *__restrict__ Cb) {
+__device__ inline void big_cores_body(const NarrowParams &p, const double *__restrict__ lam3, const int *__restrict__ info,
+                                      const double *__restrict__ VW, float *__restrict__ Cb, int blk, int nblk) {
   const int D = kD, h = p.h, g = p.g, L = p.L;
   const int r = D * h, c = D * g * L;
   const bool short_rows = r <= c;
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(kBT) void big_cores_kernel(NarrowParams p, const do
   const int *ord = info + 4;
   int ob_s_h = p.ob_s_h, ob_s_d = p.ob_s_d, oa_s_d = p.oa_s_d, oa_s_g = p.oa_s_g;
   if (p.trunc_thr > 0.0) { if (!p.left_dir) { ob_s_h = D * m; ob_s_d = m; } else { oa_s_d = m * L; oa_s_g = D * m * L; } }
-  for (int e = blockIdx.x * kBT + threadIdx.x; e < (n + len) * m; e += gridDim.x * kBT) {
+  for (int e = blk * kBT + threadIdx.x; e < (n + len) * m; e += nblk * kBT) {
     const int row = e / m, sp = e - row * m;
     const bool is_short = row < n;
     const float v = (float)(VW[(size_t)row * n + ord[sp]] * lam3[(is_short ? 1 : 2) * kBigMaxN + sp]);
@@ -752,19 +752,40 @@ __global__ __launch_bounds__(kBT) void big_cores_kernel(NarrowParams p, const do
     }
   }
 }
+__global__ __launch_bounds__(kBT) void big_cores_kernel(NarrowParams p, const double *__restrict__ lam3, const int *__restrict__ info,
+                                                       const double *__restrict__ VW, float *__restrict__ Cb) {
+  big_cores_body(p, lam3, info, VW, Cb, blockIdx.x, gridDim.x);
+}
 
 // ---- behind norm environment of the next step: Nh_new = Cb^T (Nh (x) 1_d) Cb -----------------------------------
 // 16 lanes share one output element and split its inner sum (the outputs alone are too few to fill the chip);
 // the partial sums meet by xor shuffles inside the 16-lane group, in a fixed order
-__global__ __launch_bounds__(kBT) void big_norm_T_kernel(NarrowParams p, const float *__restrict__ Cb, double *__restrict__ T2,
-                                                        const int *__restrict__ m_dev) {
-  const int D = kD, h = p.h, m = m_dev[0], DM = D * m;
+// The cores launch and T2 = (Nh (x) 1_d) . Cb in ONE launch: an element of the behind core is one product away from what the replay
+// left -- Cb[x][j] = float(VW[row(x)][ord_j] sigma_j^(+-1/2)) -- so T2 does not have to wait for the cores (a launch of one thread
+// takes 4.4 us here; the same sums as the separate launch it replaces, operand for operand).
+__global__ __launch_bounds__(kBT) void big_cores_normT_kernel(NarrowParams p, const double *__restrict__ lam3, const int *__restrict__ info,
+                                                             const double *__restrict__ VW, float *__restrict__ Cb,
+                                                             double *__restrict__ T2, int nt_blocks) {
+  if ((int)blockIdx.x >= nt_blocks) {
+    big_cores_body(p, lam3, info, VW, Cb, (int)blockIdx.x - nt_blocks, (int)gridDim.x - nt_blocks);
+    return;
+  }
+  const int D = kD, h = p.h, m = info[3], DM = D * m;
+  const int rr = D * h, cc = D * p.g * p.L;
+  const bool short_rows = rr <= cc;
+  const int n = short_rows ? rr : cc;
+  const double *vb = VW + (short_rows ? (size_t)0 : (size_t)n * n);     // the behind side's block of VW
+  const double *lam = lam3 + (short_rows ? 1 : 2) * kBigMaxN;
+  const int *ord = info + 4;
   const int sub = threadIdx.x & 15;
-  for (int e = (blockIdx.x * kBT + threadIdx.x) >> 4; e < h * DM; e += (gridDim.x * kBT) >> 4) {
+  for (int e = (blockIdx.x * kBT + threadIdx.x) >> 4; e < h * DM; e += (nt_blocks * kBT) >> 4) {
     const int j = e % DM, i = e / DM;
+    const int d = j / m, sp = j - d * m;                   // column (d, sp) of Cb viewed as [h][D m]
+    const double *col = vb + ord[sp];
+    const double ls = lam[sp];
     double acc = 0.0;
-    if (p.Nh) { for (int kk = sub; kk < h; kk += 16) acc += p.Nh[i * h + kk] * (double)Cb[(size_t)kk * DM + j]; }
-    else if (sub == 0) acc = (double)Cb[e];
+    if (p.Nh) { for (int kk = sub; kk < h; kk += 16) acc += p.Nh[i * h + kk] * (double)(float)(col[(size_t)(kk * D + d) * n] * ls); }
+    else if (sub == 0) acc = (double)(float)(col[(size_t)(i * D + d) * n] * ls);
     for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if (sub == 0) T2[e] = acc;
   }
@@ -1263,13 +1284,15 @@ bool launch_narrow_big(const NarrowParams &p, const BigScratch &s, hipStream_t s
   // (they need no LDS but share the launch's request: all of them resident beside the batch kernel of the next step, whose 157
   // workgroups leave 99 CUs)
   BIG(big_jacobi_kernel, dim3(1 + (n + len + 15) / 16), dim3(1024), big_jacobi_lds_bytes(n), a);
-  BIG(big_cores_kernel, dim3(std::min(((n + len) * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, p, (const double *)s.lam,
-      (const int *)s.info, (const double *)s.VW, s.Cb);
+  const int ncores = std::min(((n + len) * p.m + kBT - 1) / kBT, 1024);
   if (p.Nh_new) {
     const int nb2 = std::min((16 * p.h * D * p.m + kBT - 1) / kBT, 1024);
-    BIG(big_norm_T_kernel, dim3(nb2), dim3(kBT), 0, p, (const float *)s.Cb, s.T2, (const int *)(s.info + 3));
+    BIG(big_cores_normT_kernel, dim3(nb2 + ncores), dim3(kBT), 0, p, (const double *)s.lam, (const int *)s.info, (const double *)s.VW, s.Cb,
+        s.T2, nb2);
     BIG(big_norm_out_kernel, dim3(std::min((16 * p.m * p.m + kBT - 1) / kBT, 1024)), dim3(kBT), 0, p, (const float *)s.Cb,
         (const double *)s.T2, (const int *)(s.info + 3));
+  } else {
+    BIG(big_cores_kernel, dim3(ncores), dim3(kBT), 0, p, (const double *)s.lam, (const int *)s.info, (const double *)s.VW, s.Cb);
   }
 #undef BIG
   return true;

@@ -1589,9 +1589,9 @@ static int sweep_impl(tnml_ctx *c, int left_dir, int n_steps, int first_of_sweep
         f_by_z = true;
       }
       // batch kernel + reduction (a step fed by Z has neither: its contraction rides in the chain's first launch), then the update:
-      // one launch in LDS; through HBM eight in the factored form (front products [+ contraction, + next environment], merged tensor +
-      // weight decay, update, Gram, Jacobi + replay + order, cores, two for the norm environment), nine with T = Nh^T . B
-      c->sweep_launches += (zbig ? 0 : ((fused_now && npath == 0) ? 1 : 2)) + (npath == 1 ? ((Bdirect_dev || prep_ahead) ? 9 : 8) : 1);
+      // one launch in LDS; through HBM seven in the factored form (front products [+ contraction, + next environment], merged tensor +
+      // weight decay, update, Gram, Jacobi + replay + order, cores + T2, norm environment), eight with T = Nh^T . B
+      c->sweep_launches += (zbig ? 0 : ((fused_now && npath == 0) ? 1 : 2)) + (npath == 1 ? ((Bdirect_dev || prep_ahead) ? 8 : 7) : 1);
       if (zbig) c->step_launches++;           // (counted with the single-launch steps: a step that took its gradient from Z)
       c->last_bsize = (int)bsize; c->last_n = nn; c->last_h = h; c->last_g = g; c->last_left_dir = left_dir;
       if (mode == 1) {
