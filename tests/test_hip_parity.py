@@ -251,8 +251,8 @@ def test_rccl_path_single_rank(monkeypatch):
 def test_large_tensor_pipeline_matches_classic_sequence():
     """Large-tensor steps (merged tensor beyond one workgroup's LDS: bond 50 with ten labels) are pipelined too (round 3): the batch
     kernel of step k+1 runs on a second stream beside the SVD of step k and leaves the reduced pre-gradient Z_{k+1}; the step then
-    starts with the contraction A_k^T . Z (big_ext_kernel / big_contract_kernel, kernels_big.hip).  Same sums in another
-    association order: whole sweeps against the classic launch sequence (tnml_set_step_pipeline(0)), which the stepwise and
+    starts with the contraction A_k^T . Z (big_front_kernel, kernels_big.hip; the hand-offs between the two streams are sequence numbers
+    in memory or -- third run below -- events: bit-equal).  Same sums in another association order: whole sweeps against the classic launch sequence (tnml_set_step_pipeline(0)), which the stepwise and
     true-shape tests hold against the oracle."""
     N, M, b, L, D = 24, 50, 2000, 10, 2
     rng = np.random.default_rng(21)
